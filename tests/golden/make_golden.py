@@ -1,0 +1,353 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    python tests/golden/make_golden.py
+
+Nothing from the reference is copied into this repository: the script loads the
+reference's own sources at run time (poc/main.py definitions, train.py's loss
+statements and serializer, energy.py), feeds them fixed inputs and stores only
+numbers (inputs + outputs) as .npz files.
+
+What is produced:
+  g1_weights.npz   both checkpoints as flat fp64 vectors (state_dict order)
+  g2_formA_*.npz   NN_ion (poc/main.py) on a fixed batch: psi,E,lap,Hpsi,res,losses,grads
+  g3_formB.npz     train.py formulation on a fixed batch (its own statements, its `d`)
+  g4_adam_*.npz    10 torch.optim.Adam steps on stored batches (full and frozen trunk)
+  g5_energy.npz    poc/energy_R_ion.pkl table (parsed opcode-by-opcode, never unpickled)
+                   + Wind-1965 table from poc/main.py:exactE
+  g6_modelbin.npz  model.bin bytes written by train.py's serializer for the fine-tune
+                   checkpoint + energy.py's e(R) evaluated from that file
+"""
+import ast
+import hashlib
+import os
+import pickletools
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REF = os.environ.get("PINN_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+STATE_KEYS = ["Lin_H1", "Lin_H2", "Lin_out", "Lin_E1", "Lin_E2", "Lin_Eout", "netDecayL",
+              "netDecay"]
+
+
+# ----------------------------------------------------------------- loaders
+def load_main_defs():
+    """exec the definitions (imports, defs, classes) of poc/main.py; skip its script body."""
+    src = open(os.path.join(REF, "poc", "main.py")).read()
+    tree = ast.parse(src)
+    keep = []
+    seen = set()
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            if isinstance(node, ast.ImportFrom) and node.module == "scipy.integrate":
+                continue  # `simps` was removed from SciPy >= 1.14 (poc/main.py:12)
+            keep.append(node)
+        elif isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            if node.name in seen:
+                continue  # later duplicates are stale
+            seen.add(node.name)
+            keep.append(node)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    ns = {"__name__": "ref_main"}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "poc/main.py", "exec"), ns)
+    import scipy.integrate
+    ns["simps"] = lambda yv, xv: scipy.integrate.simpson(yv, x=xv)
+    ns["dtype"] = torch.double            # poc/main.py:914
+    ns["params"] = ns["set_params"]()     # poc/main.py:918
+    return ns
+
+
+def load_train_parts():
+    """train.py: helper defs, the loss statements of train()'s loop, and the serializer."""
+    src = open(os.path.join(REF, "train.py")).read()
+    tree = ast.parse(src)
+    defs, writer, loss_stmts = [], None, []
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            defs.append(node)
+        elif isinstance(node, ast.FunctionDef):
+            if node.name == "train":
+                loop = [n for n in node.body if isinstance(n, ast.While)][0]
+                started = False
+                for st in loop.body:
+                    if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Name):
+                        name = st.targets[0].id
+                        if name == "r1":
+                            started = True
+                        if started:
+                            loss_stmts.append(st)
+                        if name == "Ltot":
+                            break
+            else:
+                defs.append(node)
+        elif isinstance(node, ast.With):
+            writer = node
+    ns = {"__name__": "ref_train"}
+    exec(compile(ast.Module(body=defs, type_ignores=[]), "train.py", "exec"), ns)
+    loss_code = compile(ast.Module(body=loss_stmts, type_ignores=[]), "train.py:41-57", "exec")
+    writer_code = compile(ast.Module(body=[writer], type_ignores=[]), "train.py:112-119", "exec")
+    return ns, loss_code, writer_code
+
+
+def flat_state(sd):
+    return np.concatenate([sd[k + s].detach().cpu().numpy().ravel()
+                           for k in STATE_KEYS for s in (".weight", ".bias")])
+
+
+def sha256(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def fixed_batch(n, seed, Rhi):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-18, 18, n)
+    y = rng.uniform(-18, 18, n)
+    z = rng.uniform(-18, 18, n)
+    R = rng.uniform(0.2, Rhi, n)
+    # hand-placed hard points: close to a nucleus, the clamp value, far corners, axes
+    k = 0
+    for dr in (0.012, 0.03, 0.05, 0.2):
+        x[k], y[k], z[k] = R[k] + dr * 0.6, dr * 0.64, dr * 0.48
+        k += 1
+        x[k], y[k], z[k] = -R[k] - dr * 0.6, -dr * 0.64, dr * 0.48
+        k += 1
+    x[k], y[k], z[k] = 0.005, 0.0, 0.0        # what the clamp writes (poc/main.py:148)
+    k += 1
+    x[k], y[k], z[k] = 0.0, 0.0, 0.0
+    k += 1
+    x[k], y[k], z[k] = 17.9, -17.9, 17.9
+    k += 1
+    x[k], y[k], z[k] = -17.99, 0.3, -0.2
+    k += 1
+    return x, y, z, R
+
+
+def as_col(a, grad=False):
+    t = torch.tensor(np.asarray(a, dtype=np.float64).reshape(-1, 1), dtype=torch.float64)
+    t.requires_grad_(grad)
+    return t
+
+
+# ------------------------------------------------------------ formulation A
+def eval_form_A(ns, model, x, y, z, R):
+    params = ns["params"]
+    xt, yt, zt, Rt = as_col(x, True), as_col(y, True), as_col(z, True), as_col(R, True)
+    r1, r2 = ns["radial"](xt, yt, zt, Rt, params)
+    b1 = torch.where(r1 >= params["BCcutoff"])      # poc/main.py:392-393
+    b2 = torch.where(r2 >= params["BCcutoff"])
+    psi, E = model.parametricPsi(xt, yt, zt, Rt)
+    lap = ns["lapl"](xt, yt, zt, psi)
+    hpsi = ns["hamiltonian"](xt, yt, zt, Rt, psi, params)
+    res = hpsi - E * psi
+    model.zero_grad()
+    Ltot, Lpde, Lbc, _ = model.LossFunctions(xt, yt, zt, Rt, params, b1, b2)
+    Ltot.backward()
+    grads = np.concatenate([p.grad.detach().numpy().ravel() for p in model.parameters()])
+    mask = ((r1 >= params["BCcutoff"]).to(torch.uint8)
+            + 2 * (r2 >= params["BCcutoff"]).to(torch.uint8)).numpy().ravel().astype(np.uint8)
+    d = lambda t: t.detach().numpy().ravel().copy()
+    return dict(x=x, y=y, z=z, R=R, mask=mask, theta=flat_state(model.state_dict()),
+                psi=d(psi), E=d(E), lap=d(lap), hpsi=d(hpsi), res=d(res),
+                Ltot=float(Ltot), Lpde=float(Lpde), Lbc=float(Lbc), grad=grads)
+
+
+def gen_form_A(ns):
+    NN_ion, params = ns["NN_ion"], ns["params"]
+    x, y, z, R = fixed_batch(2048, 20250221, 4.0)
+    out = {}
+    for tag, ck in (("ionHsym", "ionHsym.pt"), ("fineTune", "ionHsym_fineTune.pt")):
+        model = NN_ion(params)
+        sd = torch.load(os.path.join(REF, "models", ck), map_location="cpu",
+                        weights_only=True)["model_state_dict"]
+        model.load_state_dict(sd)
+        out[tag] = eval_form_A(ns, model, x, y, z, R)
+    torch.manual_seed(7)
+    out["rand16"] = eval_form_A(ns, NN_ion(params), x, y, z, R)
+    torch.manual_seed(11)
+    xs, ys, zs, Rs = fixed_batch(1024, 99, 4.0)
+    out["rand64"] = eval_form_A(ns, NN_ion(params, 64, 32, 10), xs, ys, zs, Rs)
+    torch.manual_seed(13)
+    out["rand32"] = eval_form_A(ns, NN_ion(params, 32, 16, 8), xs[:512], ys[:512], zs[:512],
+                                Rs[:512])
+    for tag, dct in out.items():
+        np.savez_compressed(os.path.join(OUT, "g2_formA_%s.npz" % tag), **dct)
+        print("g2_formA_%s: Ltot=%.6e |grad|=%.3e" % (tag, dct["Ltot"],
+                                                      np.linalg.norm(dct["grad"])))
+
+
+# ------------------------------------------------------------ formulation B
+FLAT_NAMES = ["H1a", "H1b", "H2a", "H2b", "H3a", "H3b", "L1a", "L1b", "L2a", "L2b", "E1a", "E1b",
+              "E2a", "E2b", "E3a", "E3b"]
+
+
+def flat_to_state_order(tensors):
+    """train.py order/layout (in,out; H,L,E) -> state_dict order/layout ((out,in); H,E,L)."""
+    t = dict(zip(FLAT_NAMES, tensors))
+    order = ["H1", "H2", "H3", "E1", "E2", "E3", "L1", "L2"]
+    parts = []
+    for k in order:
+        parts.append(t[k + "a"].detach().numpy().T.ravel())
+        parts.append(t[k + "b"].detach().numpy().ravel())
+    return np.concatenate(parts)
+
+
+def gen_form_B():
+    ns, loss_code, _ = load_train_parts()
+    torch.manual_seed(12345)                      # train.py:75
+    ns["dtype"] = torch.double                    # train.py:76
+    nh, ne, nl = 16, 32, 10                       # train.py:85-87
+    shapes = [(2, nh), (nh,), (nh, nh), (nh,), (nh, 1), (1,), (1, nl), (nl,), (nl, 1), (1,),
+              (1, ne), (ne,), (ne, ne), (ne,), (ne, 1), (1,)]
+    tensors = [ns["ini"](*s) for s in shapes]     # train.py:88-103 (same call order)
+    x, y, z, R = fixed_batch(2048, 4242, 3.0)
+    env = dict(ns)
+    env.update(dict(zip(FLAT_NAMES, tensors)))
+    env["x"], env["y"], env["z"] = as_col(x, True), as_col(y, True), as_col(z, True)
+    env["R"] = as_col(R)
+    r1sq = (x - R) ** 2 + y ** 2 + z ** 2
+    r2sq = (x + R) ** 2 + y ** 2 + z ** 2
+    env["i1"] = torch.tensor(np.where(r1sq >= 17.5 ** 2)[0])   # train.py:38-39
+    env["i2"] = torch.tensor(np.where(r2sq >= 17.5 ** 2)[0])
+    exec(loss_code, env)                          # train.py:41-57 verbatim, at run time
+    grads = torch.autograd.grad(env["Ltot"], tensors)
+    mask = ((r1sq >= 17.5 ** 2).astype(np.uint8) + 2 * (r2sq >= 17.5 ** 2).astype(np.uint8))
+    d = lambda t: t.detach().numpy().ravel().copy()
+    np.savez_compressed(
+        os.path.join(OUT, "g3_formB.npz"), x=x, y=y, z=z, R=R, mask=mask,
+        theta=flat_to_state_order(tensors), psi=d(env["psi"]), E=d(env["e"]),
+        res=d(env["res"]), Ltot=float(env["Ltot"]), Lpde=float(env["Lpde"]),
+        Lbc=float(env["Lbc"]), grad=flat_to_state_order(grads))
+    print("g3_formB: Ltot=%.6e" % float(env["Ltot"]))
+
+
+# --------------------------------------------------------------------- Adam
+def gen_adam(ns):
+    NN_ion, params = ns["NN_ion"], ns["params"]
+    for tag, frozen, lr in (("full", False, 8e-3), ("frozen", True, 5e-4)):
+        model = NN_ion(params)
+        sd = torch.load(os.path.join(REF, "models", "ionHsym.pt"), map_location="cpu",
+                        weights_only=True)["model_state_dict"]
+        model.load_state_dict(sd)
+        if frozen:                                 # poc/main.py:384-387
+            model.freezeDecayUnit()
+            model.freezeBase()
+        opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0)  # poc/main.py:363
+        theta0 = flat_state(model.state_dict())
+        n, steps = 512, 10
+        xs, ys, zs, Rs, Ls, thetas = [], [], [], [], [], []
+        for t in range(steps):
+            x, y, z, R = fixed_batch(n, 1000 + t, 4.0)
+            xt, yt, zt, Rt = as_col(x, True), as_col(y, True), as_col(z, True), as_col(R, True)
+            r1, r2 = ns["radial"](xt, yt, zt, Rt, params)
+            b1 = torch.where(r1 >= params["BCcutoff"])
+            b2 = torch.where(r2 >= params["BCcutoff"])
+            opt.zero_grad()
+            Ltot, Lpde, Lbc, _ = model.LossFunctions(xt, yt, zt, Rt, params, b1, b2)
+            Ltot.backward()
+            opt.step()                             # poc/main.py:401-404
+            xs.append(x); ys.append(y); zs.append(z); Rs.append(R)
+            Ls.append([float(Ltot), float(Lpde), float(Lbc)])
+            thetas.append(flat_state(model.state_dict()))
+        st = opt.state_dict()["state"]
+        plist = list(model.parameters())
+        m = np.concatenate([(st[i]["exp_avg"].numpy().ravel() if i in st
+                             else np.zeros(plist[i].numel())) for i in range(len(plist))])
+        v = np.concatenate([(st[i]["exp_avg_sq"].numpy().ravel() if i in st
+                             else np.zeros(plist[i].numel())) for i in range(len(plist))])
+        np.savez_compressed(os.path.join(OUT, "g4_adam_%s.npz" % tag), theta0=theta0, lr=lr,
+                            x=np.array(xs), y=np.array(ys), z=np.array(zs), R=np.array(Rs),
+                            losses=np.array(Ls), thetas=np.array(thetas), m=m, v=v,
+                            frozen=int(frozen))
+        print("g4_adam_%s: L0=%.4e L9=%.4e" % (tag, Ls[0][0], Ls[-1][0]))
+
+
+# ------------------------------------------------------------ energy tables
+def parse_energy_pickle(path):
+    """Walk the pickle opcodes (no unpickling): a key string, later a 312-byte <f8 blob."""
+    out, key = {}, None
+    for op, arg, _ in pickletools.genops(open(path, "rb").read()):
+        if op.name == "SHORT_BINUNICODE" and arg in ("R", "E_int", "Elcao", "E_net"):
+            key = arg
+        elif op.name == "BINBYTES" and key is not None and len(arg) == 39 * 8:
+            out[key] = np.frombuffer(arg, dtype="<f8").copy()
+            key = None
+    return out
+
+
+def gen_energy(ns):
+    tab = parse_energy_pickle(os.path.join(REF, "poc", "energy_R_ion.pkl"))
+    R_exact, e_exact = ns["exactE"]()
+    np.savez_compressed(os.path.join(OUT, "g5_energy.npz"), R=tab["R"], E_int=tab["E_int"],
+                        Elcao=tab["Elcao"], E_net=tab["E_net"], R_exact=np.asarray(R_exact),
+                        E_exact=np.asarray(e_exact, dtype=np.float64))
+    print("g5_energy: E_net[0..2] =", tab["E_net"][:3])
+
+
+def gen_modelbin():
+    ns, _, writer_code = load_train_parts()
+    sd = torch.load(os.path.join(REF, "models", "ionHsym_fineTune.pt"), map_location="cpu",
+                    weights_only=True)["model_state_dict"]
+    g = lambda k: sd[k].clone()
+    # H1a = Lin_H1.weight.T, ... ; bin order H, L(gate), E
+    pairs = [("Lin_H1", "H1"), ("Lin_H2", "H2"), ("Lin_out", "H3"), ("netDecayL", "L1"),
+             ("netDecay", "L2"), ("Lin_E1", "E1"), ("Lin_E2", "E2"), ("Lin_Eout", "E3")]
+    params = []
+    for key, _ in pairs:
+        params.append(g(key + ".weight").T.contiguous())
+        params.append(g(key + ".bias"))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            env = dict(ns)
+            env["params"] = tuple(params)
+            exec(writer_code, env)                 # train.py:112-119
+            blob = open("model.bin", "rb").read()
+            os.environ["MPLBACKEND"] = "Agg"
+            np.product = np.prod                   # energy.py:18 predates NumPy 2
+            esrc = open(os.path.join(REF, "energy.py")).read()
+            eenv = {"__name__": "ref_energy"}
+            exec(compile(esrc, "energy.py", "exec"), eenv)
+            eR, Rg = eenv["e"][:, 0].copy(), eenv["R"][:, 0].copy()
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "g6_modelbin.npz"),
+                        blob=np.frombuffer(blob, dtype=np.uint8), R=Rg, e=eR)
+    print("g6_modelbin: %d bytes, e(R=0.2)=%.6f" % (len(blob), eR[0]))
+
+
+def gen_weights():
+    out = {}
+    for tag, ck in (("ionHsym", "ionHsym.pt"), ("fineTune", "ionHsym_fineTune.pt")):
+        path = os.path.join(REF, "models", ck)
+        c = torch.load(path, map_location="cpu", weights_only=True)
+        out[tag] = flat_state(c["model_state_dict"])
+        out[tag + "_sha256"] = np.frombuffer(bytes.fromhex(sha256(path)), dtype=np.uint8)
+        out[tag + "_lr"] = c["optimizer_state_dict"]["param_groups"][0]["lr"]
+        st = c["optimizer_state_dict"]["state"]
+        out[tag + "_step"] = float(st[sorted(st)[0]]["step"])
+    np.savez_compressed(os.path.join(OUT, "g1_weights.npz"), **out)
+    print("g1_weights:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
+
+
+def main():
+    torch.set_default_dtype(torch.float64)         # poc/main.py:915, train.py:77
+    torch.set_num_threads(4)
+    ns = load_main_defs()
+    gen_weights()
+    gen_form_A(ns)
+    gen_form_B()
+    gen_adam(ns)
+    gen_energy(ns)
+    gen_modelbin()
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,160 @@
+"""Pin the CPU oracle (oracle/pinn_oracle.c) to the reference.
+
+Every expected number here was produced by the reference's own code
+(tests/golden/make_golden.py ran poc/main.py's NN_ion + autograd operators,
+train.py's loss statements and torch.optim.Adam in the build container), or is
+a table the reference ships (poc/energy_R_ion.pkl, exactE).  fp64 on both
+sides, so the tolerance is round-off: 1e-12 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+TOL = 1e-12
+ARCHS = dict(ionHsym=(16, 32, 10), fineTune=(16, 32, 10), rand16=(16, 32, 10),
+             rand64=(64, 32, 10), rand32=(32, 16, 8))
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("tag", sorted(ARCHS))
+def test_formulation_A_matches_reference_autograd(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "g2_formA_%s.npz" % tag))
+    H, HE, HG = ARCHS[tag]
+    A, Hm = O.arch(H=H, HE=HE, HG=HG), O.ham_A()
+    assert O.param_count(A) == g["theta"].size
+    f = O.forward(A, Hm, g["theta"], g["x"], g["y"], g["z"], g["R"])
+    assert rel(f["psi"], g["psi"]) < TOL
+    assert rel(f["E"], g["E"]) < TOL
+    assert rel(f["lap"], g["lap"]) < TOL
+    assert rel(f["res"], g["res"]) < TOL
+    # hamiltonian() of poc/main.py:118-120 == res + E*psi
+    assert rel(f["res"] + f["E"] * f["psi"], g["hpsi"]) < TOL
+    lg = O.loss_grad(A, Hm, g["theta"], g["x"], g["y"], g["z"], g["R"], g["mask"])
+    assert abs(lg["Ltot"] / g["Ltot"] - 1) < TOL
+    assert abs(lg["Lpde"] / g["Lpde"] - 1) < TOL
+    assert abs(lg["Lbc"] / g["Lbc"] - 1) < 1e-11
+    assert rel(lg["grad"], g["grad"]) < TOL
+
+
+def test_formulation_B_matches_train_py(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_formB.npz"))
+    A, Hm = O.arch(n_pass=1, out_scale=2.0), O.ham_B()
+    f = O.forward(A, Hm, g["theta"], g["x"], g["y"], g["z"], g["R"])
+    assert rel(f["psi"], g["psi"]) < TOL
+    assert rel(f["E"], g["E"]) < TOL
+    assert rel(f["res"], g["res"]) < TOL
+    lg = O.loss_grad(A, Hm, g["theta"], g["x"], g["y"], g["z"], g["R"], g["mask"])
+    assert abs(lg["Ltot"] / g["Ltot"] - 1) < TOL
+    assert rel(lg["grad"], g["grad"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["full", "frozen"])
+def test_adam_trajectory_matches_torch_optim(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "g4_adam_%s.npz" % tag))
+    A, Hm = O.arch(), O.ham_A()
+    off, sz = O.tensor_layout(A)
+    # poc/main.py:305-319: trunk tensors 0..5 and gate tensors 12..15 frozen
+    tmask = sum(1 << t for t in range(6, 12)) if int(g["frozen"]) else (1 << 16) - 1
+    theta = g["theta0"].copy()
+    m, v = np.zeros_like(theta), np.zeros_like(theta)
+    for t in range(g["x"].shape[0]):
+        x, y, z, R = g["x"][t], g["y"][t], g["z"][t], g["R"][t]
+        r1 = np.sqrt((x - R) ** 2 + y ** 2 + z ** 2)
+        r2 = np.sqrt((x + R) ** 2 + y ** 2 + z ** 2)
+        mask = (r1 >= 17.5).astype(np.uint8) + 2 * (r2 >= 17.5).astype(np.uint8)
+        lg = O.loss_grad(A, Hm, theta, x, y, z, R, mask, trainable_mask=tmask)
+        assert abs(lg["Ltot"] / g["losses"][t, 0] - 1) < 1e-9
+        O.adam(A, theta, lg["grad"], m, v, t + 1, float(g["lr"]), trainable_mask=tmask)
+        assert rel(theta, g["thetas"][t]) < 1e-9
+    assert rel(m, g["m"]) < 1e-8
+    assert rel(v, g["v"]) < 1e-8
+    if int(g["frozen"]):
+        for t in list(range(0, 6)) + list(range(12, 16)):
+            assert np.array_equal(theta[off[t]:off[t] + sz[t]], g["theta0"][off[t]:off[t] + sz[t]])
+
+
+def test_E_net_known_answer_table(golden_dir):
+    """poc/energy_R_ion.pkl['E_net'] is the E-subnet of ionHsym_fineTune.pt at R=0.2..4.0."""
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))
+    e = np.load(os.path.join(golden_dir, "g5_energy.npz"))
+    A, Hm = O.arch(), O.ham_A()
+    R = e["R"]
+    f = O.forward(A, Hm, w["fineTune"], np.ones_like(R), np.ones_like(R), np.ones_like(R), R)
+    assert np.max(np.abs(f["E"] - e["E_net"])) < 1e-13
+    # physics sanity band vs Wind 1965: 6.4e-3 Ha for R >= 1
+    sel = e["R_exact"] >= 1.0
+    assert np.max(np.abs(f["E"][sel] - e["E_exact"][sel])) < 7e-3
+
+
+def test_energy_py_curve_from_model_bin(golden_dir):
+    """energy.py's e(R) from the reference-written model.bin == oracle E-net."""
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))
+    g = np.load(os.path.join(golden_dir, "g6_modelbin.npz"))
+    A, Hm = O.arch(), O.ham_A()
+    R = g["R"]
+    f = O.forward(A, Hm, w["fineTune"], np.ones_like(R), np.ones_like(R), np.ones_like(R), R)
+    assert np.max(np.abs(f["E"] - g["e"])) < 1e-13
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    assert O.philox([0] * 4, [0] * 2) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == \
+        [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                    [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_sampler_contract_statistics():
+    """uniform box, clamp writes x:=cutoff, BC fraction ~0.519 per nucleus."""
+    n = 200000
+    x, y, z, R, mask, counts = O.sample(12345, 0, 0, n)
+    assert x.min() >= -18 and x.max() < 18 and R.min() >= 0.2 and R.max() < 4.0
+    assert abs(x.mean()) < 0.1 and abs(x.std() - 36 / np.sqrt(12)) < 0.05
+    assert abs(counts[0] / n - 0.519) < 0.01 and abs(counts[1] / n - 0.519) < 0.01
+    assert counts == (int((mask & 1).sum()), int((mask >> 1).sum()))
+    # split streams reproduce the global stream (data-parallel shards)
+    xa = O.sample(12345, 0, 0, 1000)[0]
+    xb = O.sample(12345, 0, 500, 500)[0]
+    assert np.array_equal(xa[500:], xb)
+    # different step -> different points
+    assert not np.array_equal(O.sample(12345, 1, 0, 1000)[0], xa)
+
+
+def test_extension_tanh_multilayer_gradcheck():
+    """L>2 and tanh are not in the reference; check the oracle's adjoint by finite differences."""
+    A = O.arch(H=8, L=3, HE=6, HG=4, act=1, n_pass=2)
+    Hm = O.ham_A()
+    rng = np.random.default_rng(0)
+    P = O.param_count(A)
+    theta = rng.normal(0, 0.5, P)
+    n = 64
+    x, y, z = rng.uniform(-3, 3, (3, n))
+    R = rng.uniform(0.5, 2.0, n)
+    mask = rng.integers(0, 4, n).astype(np.uint8)
+    lg = O.loss_grad(A, Hm, theta, x, y, z, R, mask)
+    idx = rng.choice(P, 40, replace=False)
+    for k in idx:
+        h = 1e-6
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += h
+        tm[k] -= h
+        lp = O.loss_grad(A, Hm, tp, x, y, z, R, mask, want_grad=False)["Ltot"]
+        lm = O.loss_grad(A, Hm, tm, x, y, z, R, mask, want_grad=False)["Ltot"]
+        fd = (lp - lm) / (2 * h)
+        assert abs(fd - lg["grad"][k]) < 1e-6 * max(1.0, abs(fd)), (k, fd, lg["grad"][k])
+    # Laplacian stream vs finite differences of psi
+    f0 = O.forward(A, Hm, theta, x, y, z, R)
+    h = 1e-4
+    lap = np.zeros(n)
+    for dx, dy, dz in ((h, 0, 0), (0, h, 0), (0, 0, h)):
+        fp = O.forward(A, Hm, theta, x + dx, y + dy, z + dz, R)["psi"]
+        fm = O.forward(A, Hm, theta, x - dx, y - dy, z - dz, R)["psi"]
+        lap += (fp - 2 * f0["psi"] + fm) / h ** 2
+    assert np.max(np.abs(lap - f0["lap"])) < 1e-5 * max(1.0, np.max(np.abs(f0["lap"])))

@@ -1,0 +1,1079 @@
+// pinn_kernels.hip -- gfx950 kernels and the C ABI of include/pinn.h (fp32 parity path).
+//
+// Kernel map:
+//   k_sample      K3  Philox box sampler + nucleus clamp + BC masks/counts (train.py:26-39)
+//   k_rnet_fwd        E(R), g(R) per point: the two R-only sub-nets (poc/main.py:249-253,262-264)
+//   k_trunk       K1/K2 fused features -> 5-stream trunk MLP -> psi, lap psi, residual, loss
+//                     seeds -> full reverse pass; weight gradients contracted over the wave's
+//                     64 points on the f32 MFMA pipe (train.py:41-57,71)
+//   k_rnet_bwd        reverse pass of the R-only sub-nets from per-point dL/dE, dL/dg
+//   k_reduce          fixed-order second-stage reduction of per-block partials (deterministic)
+//   k_adam        K4  Adam + best-so-far snapshot (train.py:23,58-60,72)
+//
+// Execution shape: one collocation point per lane (wave64).  Weights are read
+// with wave-uniform addresses, so hipcc places them in SGPRs (s_load through
+// the scalar cache) and every v_fmac takes its weight as a free scalar operand:
+// no LDS or VGPR is spent on the weights.  The only cross-lane work is the
+// weight-gradient contraction over points.  It is not done on the VALU: each
+// wave transposes (adjoint, input) vectors through a private LDS tile and
+// issues v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), accumulating 16x16
+// gradient tiles in registers for the whole kernel; the matrix pipe runs beside
+// the VALU, so the contraction is nearly free.  Per-block partials are written
+// once and summed in fixed order: results are bitwise reproducible.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/pinn.h"
+#include "pinn_math.h"
+
+using namespace pinn;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;             // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kPitch = 68;              // floats per staged row: 64 points + 4 pad (272 B, 16-B aligned)
+
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HEAD = 2 };
+
+// ---------------------------------------------------------------- wave tiles
+// D[16x16] += sum over the wave's 64 points of U[j][pt] * V[i][pt].
+// Staging image: row r of a vector (one value per lane) at buf[r*kPitch + lane].
+// Fragment of lane (g = lane>>4, c = lane&15): the 16 consecutive points
+// 16g..16g+15 of row c -> MFMA step t contracts the four points {16g+t}.
+__device__ __forceinline__ void stage_row(float* buf, int row, float v, int lane)
+{
+    buf[row * kPitch + lane] = v;
+}
+
+template <int N>
+__device__ __forceinline__ void stage_rows(float* buf, int row0, const float (&v)[N], int lane)
+{
+#pragma unroll
+    for (int j = 0; j < N; j++) buf[(row0 + j) * kPitch + lane] = v[j];
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS operations of one wave execute in issue order; this only stops the
+    // compiler from moving the fragment reads above the staging writes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct Frag {
+    float v[16];
+};
+
+__device__ __forceinline__ void load_frag(const float* buf, int rowblock, int lane, Frag& f)
+{
+    const int c = lane & 15, g = lane >> 4;
+    const float4* p = reinterpret_cast<const float4*>(buf + (rowblock * 16 + c) * kPitch + 16 * g);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float4 t = p[q];
+        f.v[4 * q + 0] = t.x;
+        f.v[4 * q + 1] = t.y;
+        f.v[4 * q + 2] = t.z;
+        f.v[4 * q + 3] = t.w;
+    }
+}
+
+// fragment of a row that is constant over points: value on row `row`, 0 elsewhere
+__device__ __forceinline__ void const_frag(int row, float value, int lane, Frag& f)
+{
+    const float x = (lane & 15) == row ? value : 0.0f;
+#pragma unroll
+    for (int t = 0; t < 16; t++) f.v[t] = x;
+}
+
+__device__ __forceinline__ void mma(f32x4& acc, const Frag& a, const Frag& b)
+{
+#pragma unroll
+    for (int t = 0; t < 16; t++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[t], b.v[t], acc, 0, 0, 0);
+}
+
+// tile element (row = 4*(lane>>4) + r, col = lane&15) lives in acc[r]
+__device__ __forceinline__ void tile_store(const f32x4& acc, float* dst, int row_stride,
+                                           int col_stride, int nrow, int ncol, int lane, bool add)
+{
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * g + r;
+        if (row < nrow && c < ncol) {
+            float* p = dst + row * row_stride + c * col_stride;
+            *p = add ? *p + acc[r] : acc[r];
+        }
+    }
+}
+
+// Weights are loop-invariant, so LICM would hoist all P scalar loads out of the
+// persistent point loop and spill ~P SGPRs.  Passing the pointer through an empty
+// asm offset per phase keeps each phase's s_loads next to their use.
+__device__ __forceinline__ const float* launder(const float* __restrict__ p)
+{
+    int z;  // an opaque zero: keeps the pointer's address space / noalias provenance
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return p + z;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+// ------------------------------------------------------------- trunk kernel
+template <int H, int L>
+struct TrunkSink {
+    static constexpr int HT = H / 16;
+    float* U;
+    float* V;
+    int lane;
+    f32x4 tW[L - 1][HT][HT];  // W_l-bar, l = 1..L-1
+    f32x4 tB[L - 1][HT];      // col 0: b_l-bar
+    f32x4 tW0[HT];            // cols 0,1: W_0-bar; col 2: b_0-bar
+    f32x4 tOut[HT];           // col 0: wout-bar
+
+    __device__ __forceinline__ void zero()
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < L - 1; l++)
+#pragma unroll
+            for (int a = 0; a < HT; a++) {
+                tB[l][a] = z;
+#pragma unroll
+                for (int b = 0; b < HT; b++) tW[l][a][b] = z;
+            }
+#pragma unroll
+        for (int a = 0; a < HT; a++) { tW0[a] = z; tOut[a] = z; }
+    }
+
+    __device__ __forceinline__ void out_weight(const float (&t)[H])
+    {
+        stage_rows<H>(U, 0, t, lane);
+        wave_lds_sync();
+        Frag one;
+        const_frag(0, 1.0f, lane, one);
+#pragma unroll
+        for (int a = 0; a < HT; a++) {
+            Frag fa;
+            load_frag(U, a, lane, fa);
+            mma(tOut[a], fa, one);
+        }
+    }
+
+    __device__ __forceinline__ void weight(int l, int s, const float (&ab)[H], const float (&oin)[H])
+    {
+        stage_rows<H>(U, 0, ab, lane);
+        stage_rows<H>(V, 0, oin, lane);
+        wave_lds_sync();
+        Frag fa[HT];
+#pragma unroll
+        for (int a = 0; a < HT; a++) load_frag(U, a, lane, fa[a]);
+#pragma unroll
+        for (int b = 0; b < HT; b++) {
+            Frag fb;
+            load_frag(V, b, lane, fb);
+#pragma unroll
+            for (int a = 0; a < HT; a++) mma(tW[l - 1][a][b], fa[a], fb);
+        }
+        if (s == 0) {
+            Frag one;
+            const_frag(0, 1.0f, lane, one);
+#pragma unroll
+            for (int a = 0; a < HT; a++) mma(tB[l - 1][a], fa[a], one);
+        }
+    }
+
+    __device__ __forceinline__ void weight0(int s, const float (&ab)[H], float in0, float in1)
+    {
+        stage_rows<H>(U, 0, ab, lane);
+        stage_row(V, 0, in0, lane);
+        stage_row(V, 1, in1, lane);
+        stage_row(V, 2, s == 0 ? 1.0f : 0.0f, lane);
+        wave_lds_sync();
+        Frag fb;
+        load_frag(V, 0, lane, fb);  // rows 3..15 hold stale finite data: unused columns
+#pragma unroll
+        for (int a = 0; a < HT; a++) {
+            Frag fa;
+            load_frag(U, a, lane, fa);
+            mma(tW0[a], fa, fb);
+        }
+    }
+
+    // add this wave's tiles into the block gradient image g (theta order)
+    __device__ __forceinline__ void dump(float* g, bool add)
+    {
+        using Lay = TrunkLayout<H, L>;
+#pragma unroll
+        for (int l = 1; l < L; l++)
+#pragma unroll
+            for (int a = 0; a < HT; a++) {
+#pragma unroll
+                for (int b = 0; b < HT; b++)
+                    tile_store(tW[l - 1][a][b], g + Lay::W(l) + (16 * a) * H + 16 * b, H, 1, 16, 16,
+                               lane, add);
+                tile_store(tB[l - 1][a], g + Lay::b(l) + 16 * a, 1, 0, 16, 1, lane, add);
+            }
+#pragma unroll
+        for (int a = 0; a < HT; a++) {
+            tile_store(tW0[a], g + Lay::W(0) + (16 * a) * 2, 2, 1, 16, 2, lane, add);
+            // column 2 of tW0 is the layer-0 bias
+            {
+                const int c = lane & 15, gq = lane >> 4;
+                if (c == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float* p = g + Lay::b(0) + 16 * a + 4 * gq + r;
+                        *p = add ? *p + tW0[a][r] : tW0[a][r];
+                    }
+                }
+            }
+            tile_store(tOut[a], g + Lay::Wout + 16 * a, 1, 0, 16, 1, lane, add);
+        }
+    }
+};
+
+struct TrunkArgs {
+    const float *x, *y, *z, *R;
+    const float *E, *g;       // from k_rnet_fwd
+    const uint8_t* mask;      // may be null
+    int64_t n;
+    float a, b, c, P, out_scale, invN, invN1, invN2;
+    const long long* bc_counts;  // optional device int64[2]: overrides invN1/invN2
+    float *psi, *lap, *res;   // MODE_FWD outputs (nullable)
+    float *Eb, *gb;           // MODE_BWD / MODE_HEAD per-point adjoints
+    float* partial;           // [gridDim.x][stride]: trunk grads then 3 loss terms
+    int stride;
+};
+
+template <int H, int L, int ACT, int NPASS, int MODE>
+__global__ __launch_bounds__(kBlock, 2) void k_trunk(const float* __restrict__ th, TrunkArgs A)
+{
+    using Lay = TrunkLayout<H, L>;
+    constexpr int PT = Lay::size;
+    __shared__ __attribute__((aligned(16))) float smem[kWavesPerBlock * 2 * H * kPitch + PT + 16];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* gimg = smem + kWavesPerBlock * 2 * H * kPitch;  // block gradient image + 4 scalars/wave
+
+    TrunkSink<H, L> sink;
+    sink.U = smem + wave * 2 * H * kPitch;
+    sink.V = sink.U + H * kPitch;
+    sink.lane = lane;
+    if (MODE == MODE_BWD) {
+        sink.zero();
+        for (int k = lane; k < 2 * H * kPitch; k += kWave) sink.U[k] = 0.0f;
+    }
+    float acc_bout = 0.f, acc_pde = 0.f, acc_bc1 = 0.f, acc_bc2 = 0.f;
+    float invN1 = A.invN1, invN2 = A.invN2;
+    if (MODE != MODE_FWD && A.bc_counts) {
+        const long long c1 = A.bc_counts[0], c2 = A.bc_counts[1];
+        invN1 = c1 > 0 ? 1.0f / (float)c1 : 0.0f;
+        invN2 = c2 > 0 ? 1.0f / (float)c2 : 0.0f;
+    }
+
+    for (int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kWave; base < A.n;
+         base += (int64_t)gridDim.x * kBlock) {
+        const int64_t idx = base + lane;
+        const bool valid = idx < A.n;
+        const int64_t id = valid ? idx : A.n - 1;
+        const float xv = A.x[id], yv = A.y[id], zv = A.z[id], Rv = A.R[id];
+        const float Ev = A.E[id], gv = A.g[id];
+        float m1 = 0.f, m2 = 0.f;
+        if (MODE != MODE_FWD && A.mask) {
+            const uint8_t mk = A.mask[id];
+            m1 = float(mk & 1);
+            m2 = float((mk >> 1) & 1);
+        }
+        float inA[2][5], inB[2][5], ri1, ri2;
+        orbital<float>(xv - Rv, yv, zv, inA[0], ri1);
+        orbital<float>(xv + Rv, yv, zv, inA[1], ri2);
+#pragma unroll
+        for (int s = 0; s < 5; s++) { inB[0][s] = inA[1][s]; inB[1][s] = inA[0][s]; }
+        const float F = inA[0][0] + A.P * inA[1][0];
+        const float lapF = inA[0][4] + A.P * inA[1][4];
+
+        TrunkPass<H, L, ACT, float> tp;
+        Tail<float> t;
+        float SvA = 0.f, SlA = 0.f;
+        // NPASS == 2 stages: 0 = forward(f1,f2); 1 = forward(f2,f1) + tail + reverse of that
+        // pass; 2 = forward(f1,f2) again + its reverse.  One copy of the code, three trips:
+        // the second pass's state replaces the first's, so the live set is one pass.
+        constexpr int nstage = NPASS == 2 ? (MODE == MODE_BWD ? 3 : 2) : 1;
+#pragma unroll 1
+        for (int st = 0; st < nstage; st++) {
+            const bool useB = NPASS == 2 && st == 1;
+            float in[2][5];
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int s = 0; s < 5; s++) in[c][s] = useB ? inB[c][s] : inA[c][s];
+            float Sv = 0.f, Sl = 0.f;
+            tp.forward(launder(th), in, Sv, Sl);
+            const bool do_tail = NPASS == 1 || st == 1;
+            if (NPASS == 2 && st == 0) { SvA = Sv; SlA = Sl; }
+            if (do_tail) {
+                if (NPASS == 2) { Sv = SvA + A.P * Sv; Sl = SlA + A.P * Sl; }
+                const float N = A.out_scale * Sv + th[Lay::bout];
+                const float lapN = A.out_scale * Sl;
+                tail<float>(N, lapN, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1, m2, A.invN,
+                            invN1, invN2, valid ? 1.0f : 0.0f, t);
+                if (MODE == MODE_FWD) {
+                    if (valid) {
+                        if (A.psi) A.psi[idx] = t.psi;
+                        if (A.lap) A.lap[idx] = t.lap;
+                        if (A.res) A.res[idx] = t.res;
+                    }
+                } else {
+                    if (valid) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+                    acc_pde += t.l_pde;
+                    acc_bc1 += t.l_bc1;
+                    acc_bc2 += t.l_bc2;
+                    acc_bout += t.Nb;
+                }
+            }
+            if (MODE == MODE_BWD && (NPASS == 1 || st >= 1)) {
+                const float pw = useB ? A.P : 1.0f;
+                tp.backward(launder(th), in, A.out_scale * pw * t.Nb, A.out_scale * pw * t.lapNb, sink);
+            }
+        }
+    }
+
+    if (MODE == MODE_FWD) return;
+    // ---- block reduction in fixed wave order, then one partial row per block
+    float* sc = gimg + PT;
+    const float s0 = wave_sum(acc_pde), s1 = wave_sum(acc_bc1), s2 = wave_sum(acc_bc2),
+                s3 = wave_sum(acc_bout);
+    for (int w = 0; w < kWavesPerBlock; w++) {
+        if (wave == w) {
+            if (MODE == MODE_BWD) sink.dump(gimg, w != 0);
+            if (lane == 0) {
+                if (w == 0) { sc[0] = s0; sc[1] = s1; sc[2] = s2; sc[3] = s3; }
+                else { sc[0] += s0; sc[1] += s1; sc[2] += s2; sc[3] += s3; }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = A.partial + (size_t)blockIdx.x * A.stride;
+    if (MODE == MODE_BWD) {
+        for (int k = threadIdx.x; k < PT; k += kBlock) out[k] = k == Lay::bout ? sc[3] : gimg[k];
+    } else {
+        for (int k = threadIdx.x; k < PT; k += kBlock) out[k] = 0.0f;
+    }
+    if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
+}
+
+// -------------------------------------------------------------- R-only nets
+template <int HE, int HG, int ACT>
+__global__ __launch_bounds__(kBlock) void k_rnet_fwd(const float* __restrict__ th_r,
+                                                     const float* __restrict__ R, int64_t n,
+                                                     float* __restrict__ E, float* __restrict__ g,
+                                                     float* __restrict__ E_user)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kBlock) {
+        Rnet<HE, HG, ACT, float> rn;
+        float e, gg;
+        rn.forward(launder(th_r), R[i], e, gg);
+        E[i] = e;
+        g[i] = gg;
+        if (E_user) E_user[i] = e;
+    }
+}
+
+template <int HE, int HG>
+struct RnetSink {
+    static constexpr int ET = (HE + 15) / 16;
+    float* U;
+    float* V;
+    int lane;
+    f32x4 tE2[ET][ET], tbE2[ET], tE3[ET], tE1[ET], tG2, tG1;
+    float bE3, bG2;
+
+    __device__ __forceinline__ void zero()
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < ET; a++) {
+            tbE2[a] = z; tE3[a] = z; tE1[a] = z;
+#pragma unroll
+            for (int b = 0; b < ET; b++) tE2[a][b] = z;
+        }
+        tG2 = z; tG1 = z;
+        bE3 = 0.f; bG2 = 0.f;
+    }
+    __device__ __forceinline__ void e3(const float (&t3)[HE], float Eb)
+    {
+        stage_rows<HE>(U, 0, t3, lane);
+        wave_lds_sync();
+        Frag one;
+        const_frag(0, 1.0f, lane, one);
+#pragma unroll
+        for (int a = 0; a < ET; a++) {
+            Frag fa;
+            load_frag(U, a, lane, fa);
+            mma(tE3[a], fa, one);
+        }
+        bE3 += Eb;
+    }
+    __device__ __forceinline__ void e2(const float (&a2)[HE], const float (&h1)[HE])
+    {
+        stage_rows<HE>(U, 0, a2, lane);
+        stage_rows<HE>(V, 0, h1, lane);
+        wave_lds_sync();
+        Frag fa[ET], one;
+        const_frag(0, 1.0f, lane, one);
+#pragma unroll
+        for (int a = 0; a < ET; a++) {
+            load_frag(U, a, lane, fa[a]);
+            mma(tbE2[a], fa[a], one);
+        }
+#pragma unroll
+        for (int b = 0; b < ET; b++) {
+            Frag fb;
+            load_frag(V, b, lane, fb);
+#pragma unroll
+            for (int a = 0; a < ET; a++) mma(tE2[a][b], fa[a], fb);
+        }
+    }
+    // cols 0,1 of the tile: sum a*R, sum a
+    template <int N>
+    __device__ __forceinline__ void times_R_and_1(f32x4* tiles, const float (&a)[N], float Rv)
+    {
+        stage_rows<N>(U, 0, a, lane);
+        stage_row(V, 0, Rv, lane);
+        stage_row(V, 1, 1.0f, lane);
+        wave_lds_sync();
+        Frag fb;
+        load_frag(V, 0, lane, fb);
+#pragma unroll
+        for (int t = 0; t < (N + 15) / 16; t++) {
+            Frag fa;
+            load_frag(U, t, lane, fa);
+            mma(tiles[t], fa, fb);
+        }
+    }
+    __device__ __forceinline__ void e1(const float (&a1)[HE], float Rv) { times_R_and_1<HE>(tE1, a1, Rv); }
+    __device__ __forceinline__ void g1(const float (&ag)[HG], float Rv) { times_R_and_1<HG>(&tG1, ag, Rv); }
+    __device__ __forceinline__ void g2(const float (&tg)[HG], float gb)
+    {
+        stage_rows<HG>(U, 0, tg, lane);
+        wave_lds_sync();
+        Frag one, fa;
+        const_frag(0, 1.0f, lane, one);
+        load_frag(U, 0, lane, fa);
+        mma(tG2, fa, one);
+        bG2 += gb;
+    }
+    __device__ __forceinline__ void dump(float* g, bool add)
+    {
+        const RnetLayout Lo{HE, HG};
+#pragma unroll
+        for (int a = 0; a < ET; a++) {
+            const int nr = HE - 16 * a < 16 ? HE - 16 * a : 16;
+#pragma unroll
+            for (int b = 0; b < ET; b++) {
+                const int nc = HE - 16 * b < 16 ? HE - 16 * b : 16;
+                tile_store(tE2[a][b], g + Lo.WE2() + (16 * a) * HE + 16 * b, HE, 1, nr, nc, lane, add);
+            }
+            tile_store(tbE2[a], g + Lo.bE2() + 16 * a, 1, 0, nr, 1, lane, add);
+            tile_store(tE3[a], g + Lo.WE3() + 16 * a, 1, 0, nr, 1, lane, add);
+            // tE1: col 0 -> WE1-bar, col 1 -> bE1-bar (bE1 follows WE1 at distance HE)
+            tile_store(tE1[a], g + Lo.WE1() + 16 * a, 1, HE, nr, 2, lane, add);
+        }
+        tile_store(tG2, g + Lo.WG2(), 1, 0, HG, 1, lane, add);
+        tile_store(tG1, g + Lo.WG1(), 1, HG, HG, 2, lane, add);
+    }
+};
+
+template <int HE, int HG, int ACT>
+__global__ __launch_bounds__(kBlock) void k_rnet_bwd(const float* __restrict__ th_r,
+                                                     const float* __restrict__ R,
+                                                     const float* __restrict__ Eb,
+                                                     const float* __restrict__ gb, int64_t n,
+                                                     float* __restrict__ partial, int stride)
+{
+    constexpr int HR = ((HE > HG ? HE : HG) + 15) / 16 * 16;  // staged rows
+    constexpr RnetLayout Lo{HE, HG};
+    constexpr int PR = Lo.size();
+    __shared__ __attribute__((aligned(16))) float smem_r[kWavesPerBlock * 2 * HR * kPitch + PR + 16];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* gimg = smem_r + kWavesPerBlock * 2 * HR * kPitch;
+    RnetSink<HE, HG> sink;
+    sink.U = smem_r + wave * 2 * HR * kPitch;
+    sink.V = sink.U + HR * kPitch;
+    sink.lane = lane;
+    sink.zero();
+    for (int k = lane; k < 2 * HR * kPitch; k += kWave) sink.U[k] = 0.0f;
+
+    for (int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kWave; base < n;
+         base += (int64_t)gridDim.x * kBlock) {
+        const int64_t idx = base + lane;
+        const bool valid = idx < n;
+        const int64_t id = valid ? idx : n - 1;
+        const float Rv = R[id];
+        const float eb = valid ? Eb[id] : 0.0f, gbv = valid ? gb[id] : 0.0f;
+        Rnet<HE, HG, ACT, float> rn;
+        float e, gg;
+        rn.forward(launder(th_r), Rv, e, gg);
+        rn.backward(launder(th_r), Rv, eb, gbv, sink);
+    }
+    const float sE3 = wave_sum(sink.bE3), sG2 = wave_sum(sink.bG2);
+    for (int w = 0; w < kWavesPerBlock; w++) {
+        if (wave == w) {
+            sink.dump(gimg, w != 0);
+            if (lane == 0) {
+                float* sc = gimg + PR;
+                if (w == 0) { sc[0] = sE3; sc[1] = sG2; }
+                else { sc[0] += sE3; sc[1] += sG2; }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = partial + (size_t)blockIdx.x * stride;
+    for (int k = threadIdx.x; k < PR; k += kBlock)
+        out[k] = k == Lo.bE3() ? gimg[PR] : (k == Lo.bG2() ? gimg[PR + 1] : gimg[k]);
+}
+
+// --------------------------------------------------------- reduce / Adam / sample
+// out[e] = sum_b partial[b][e] in fixed order; frozen tensors -> 0
+__global__ void k_reduce(const float* __restrict__ partT, int nbT, int strideT, int PT,
+                         const float* __restrict__ partR, int nbR, int strideR, int PR,
+                         const uint8_t* __restrict__ tensor_of, uint64_t trainable_mask,
+                         float* __restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = PT + PR;
+    if (e >= P + 3) return;
+    float s = 0.f;
+    if (e < PT) {
+        for (int b = 0; b < nbT; b++) s += partT[(size_t)b * strideT + e];
+    } else if (e < P) {
+        for (int b = 0; b < nbR; b++) s += partR[(size_t)b * strideR + (e - PT)];
+    } else {
+        for (int b = 0; b < nbT; b++) s += partT[(size_t)b * strideT + PT + (e - P)];
+    }
+    if (e < P && !((trainable_mask >> tensor_of[e]) & 1)) s = 0.f;
+    out[e] = s;
+}
+
+__global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
+                                               const float* __restrict__ grad,
+                                               float* __restrict__ m, float* __restrict__ v,
+                                               int32_t* __restrict__ step_count, int P, float lr,
+                                               float b1, float b2, float eps,
+                                               const uint8_t* __restrict__ tensor_of,
+                                               uint64_t trainable_mask,
+                                               float* __restrict__ best_theta,
+                                               float* __restrict__ best_loss)
+{
+    const int step = *step_count + 1;
+    const float ltot = grad[P] + grad[P + 1] + grad[P + 2];
+    const bool better = best_loss != nullptr && ltot < *best_loss;
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2s = (float)(1.0 / sqrt(bc2));
+    __syncthreads();  // every thread has read step_count / best_loss
+    for (int k = threadIdx.x; k < P; k += blockDim.x) {
+        const float th = theta[k];
+        if (better && best_theta) best_theta[k] = th;  // train.py:58-60: params the loss was taken at
+        if (!((trainable_mask >> tensor_of[k]) & 1)) continue;
+        const float g = grad[k];
+        const float mk = b1 * m[k] + (1.0f - b1) * g;
+        const float vk = b2 * v[k] + (1.0f - b2) * g * g;
+        m[k] = mk;
+        v[k] = vk;
+        const float denom = sqrtf(vk) * inv_bc2s + eps;
+        theta[k] = th - step_size * (mk / denom);
+    }
+    if (threadIdx.x == 0) {
+        *step_count = step;
+        if (better) *best_loss = ltot;
+    }
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&o)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t step, int64_t first,
+                                                   int64_t n, float box, float Rlo, float Rhi,
+                                                   float cutoff, float bc_cutoff,
+                                                   float* __restrict__ x, float* __restrict__ y,
+                                                   float* __restrict__ z, float* __restrict__ R,
+                                                   uint8_t* __restrict__ mask,
+                                                   unsigned long long* __restrict__ counts)
+{
+    const float two_box = box + box, dR = Rhi - Rlo;
+    const float cut2 = cutoff * cutoff, bc2 = bc_cutoff * bc_cutoff;
+    unsigned c1 = 0, c2 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kBlock) {
+        const uint64_t gi = (uint64_t)(first + i);
+        uint32_t o[4];
+        philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)step, (uint32_t)(step >> 32),
+                      (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        float xv = __fmaf_rn(two_box, u01(o[0]), -box);
+        const float yv = __fmaf_rn(two_box, u01(o[1]), -box);
+        const float zv = __fmaf_rn(two_box, u01(o[2]), -box);
+        const float Rv = __fmaf_rn(dR, u01(o[3]), Rlo);
+        const float yz = __fmaf_rn(yv, yv, __fmul_rn(zv, zv));
+        float d1 = __fsub_rn(xv, Rv), d2 = __fadd_rn(xv, Rv);
+        float r1sq = __fmaf_rn(d1, d1, yz), r2sq = __fmaf_rn(d2, d2, yz);
+        if (r1sq < cut2 || r2sq < cut2) xv = cutoff;  // train.py:34-35
+        d1 = __fsub_rn(xv, Rv);
+        d2 = __fadd_rn(xv, Rv);
+        r1sq = __fmaf_rn(d1, d1, yz);
+        r2sq = __fmaf_rn(d2, d2, yz);
+        const uint8_t mk = (uint8_t)((r1sq >= bc2 ? 1 : 0) | (r2sq >= bc2 ? 2 : 0));
+        x[i] = xv; y[i] = yv; z[i] = zv; R[i] = Rv;
+        if (mask) mask[i] = mk;
+        c1 += mk & 1;
+        c2 += (mk >> 1) & 1;
+    }
+    if (counts) {
+        // integer sums: order-independent, so atomics stay deterministic
+        __shared__ unsigned sh[2];
+        if (threadIdx.x < 2) sh[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned w1 = c1, w2 = c2;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            w1 += (unsigned)__shfl_xor((int)w1, off, kWave);
+            w2 += (unsigned)__shfl_xor((int)w2, off, kWave);
+        }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&sh[0], w1); atomicAdd(&sh[1], w2); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&counts[0], (unsigned long long)sh[0]);
+            atomicAdd(&counts[1], (unsigned long long)sh[1]);
+        }
+    }
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+struct pinn_handle {
+    pinn_arch arch;
+    int device;
+    int64_t max_points;
+    int PT, PR, P;
+    int nbT, nbR;           // persistent grid sizes
+    int strideT, strideR;
+    float *E, *g, *Eb, *gb; // per-point scratch
+    float *partT, *partR;   // per-block partials
+    uint8_t* tensor_of;     // [P] tensor index of each parameter
+    uint64_t trunk_tensors; // bits of the trunk tensors
+    int prof_slots;          // 0 = off
+    int64_t prof_calls;      // calls recorded since enable
+    hipEvent_t* ev;          // 2 * prof_slots events
+    char err[256];
+};
+
+static int trunk_size(const pinn_arch* a) { return 3 * a->H + (a->L - 1) * (a->H * a->H + a->H) + a->H + 1; }
+static int rnet_size(const pinn_arch* a) { return 4 * a->HE + a->HE * a->HE + 1 + 3 * a->HG + 1; }
+
+static int arch_ok(const pinn_arch* a)
+{
+    if (!a) return 0;
+    if (a->H < 1 || a->L < 2 || a->L > 8 || a->HE < 1 || a->HG < 1) return 0;
+    if (a->act != PINN_ACT_SIGMOID && a->act != PINN_ACT_TANH) return 0;
+    if (a->n_pass != 1 && a->n_pass != 2) return 0;
+    return 1;
+}
+
+extern "C" int64_t pinn_param_count(const pinn_arch* a)
+{
+    if (!arch_ok(a)) return PINN_ERR_ARG;
+    return (int64_t)trunk_size(a) + rnet_size(a);
+}
+
+extern "C" int32_t pinn_tensor_count(const pinn_arch* a)
+{
+    if (!arch_ok(a)) return PINN_ERR_ARG;
+    return 2 * (a->L + 1) + 6 + 4;
+}
+
+extern "C" int pinn_tensor_layout(const pinn_arch* a, int64_t* off, int64_t* sz)
+{
+    if (!arch_ok(a) || !off || !sz) return PINN_ERR_ARG;
+    int t = 0;
+    int64_t o = 0;
+    const int H = a->H, HE = a->HE, HG = a->HG;
+    auto push = [&](int64_t n) { off[t] = o; sz[t] = n; o += n; t++; };
+    for (int l = 0; l < a->L; l++) { push((int64_t)H * (l == 0 ? 2 : H)); push(H); }
+    push(H); push(1);
+    push(HE); push(HE); push((int64_t)HE * HE); push(HE); push(HE); push(1);
+    push(HG); push(HG); push(HG); push(1);
+    return PINN_OK;
+}
+
+extern "C" const char* pinn_strerror(int s)
+{
+    switch (s) {
+        case PINN_OK: return "ok";
+        case PINN_ERR_ARG: return "invalid argument";
+        case PINN_ERR_UNSUPPORTED: return "unsupported architecture or option";
+        case PINN_ERR_HIP: return "HIP runtime error";
+        case PINN_ERR_CAPACITY: return "batch larger than max_points given at pinn_create";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* pinn_last_error(const pinn_handle* h) { return h ? h->err : "null handle"; }
+
+static int fail(pinn_handle* h, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (h) {
+        if (e != hipSuccess) snprintf(h->err, sizeof h->err, "%s: %s", what, hipGetErrorString(e));
+        else snprintf(h->err, sizeof h->err, "%s", what);
+    }
+    return code;
+}
+
+#define HIPCHK(h, call)                                                   \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return fail(h, PINN_ERR_HIP, #call, e_);    \
+    } while (0)
+
+// ---- template dispatch ---------------------------------------------------
+namespace {
+
+struct TrunkKey { int H, L, act, npass, mode; };
+
+template <int H, int L, int ACT, int NPASS, int MODE>
+static hipError_t launch_trunk_t(const float* theta, const TrunkArgs& A, int grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_trunk<H, L, ACT, NPASS, MODE>), dim3(grid), dim3(kBlock), 0, st, theta, A);
+    return hipGetLastError();
+}
+
+template <int H, int L>
+static int launch_trunk_HL(const TrunkKey& k, const float* theta, const TrunkArgs& A, int grid, hipStream_t st, hipError_t* e)
+{
+#define PINN_CASE(ACT, NP, MD)                                                     \
+    if (k.act == ACT && k.npass == NP && k.mode == MD) {                           \
+        *e = launch_trunk_t<H, L, ACT, NP, MD>(theta, A, grid, st);                      \
+        return 1;                                                                  \
+    }
+    PINN_CASE(ACT_SIGMOID, 2, MODE_FWD) PINN_CASE(ACT_SIGMOID, 2, MODE_BWD) PINN_CASE(ACT_SIGMOID, 2, MODE_HEAD)
+    PINN_CASE(ACT_SIGMOID, 1, MODE_FWD) PINN_CASE(ACT_SIGMOID, 1, MODE_BWD) PINN_CASE(ACT_SIGMOID, 1, MODE_HEAD)
+    PINN_CASE(ACT_TANH, 2, MODE_FWD) PINN_CASE(ACT_TANH, 2, MODE_BWD) PINN_CASE(ACT_TANH, 2, MODE_HEAD)
+    PINN_CASE(ACT_TANH, 1, MODE_FWD) PINN_CASE(ACT_TANH, 1, MODE_BWD) PINN_CASE(ACT_TANH, 1, MODE_HEAD)
+#undef PINN_CASE
+    return 0;
+}
+
+static int launch_trunk(const TrunkKey& k, const float* theta, const TrunkArgs& A, int grid, hipStream_t st, hipError_t* e)
+{
+    if (k.H == 16 && k.L == 2) return launch_trunk_HL<16, 2>(k, theta, A, grid, st, e);
+    if (k.H == 16 && k.L == 3) return launch_trunk_HL<16, 3>(k, theta, A, grid, st, e);
+    return 0;
+}
+
+static bool trunk_supported(int H, int L) { return H == 16 && (L == 2 || L == 3); }
+static bool rnet_supported(int HE, int HG) { return (HE == 32 && HG == 10) || (HE == 16 && HG == 8); }
+
+template <int HE, int HG>
+static int launch_rnet_fwd_s(int act, const float* th, const float* R, int64_t n, float* E, float* g,
+                             float* Eu, int grid, hipStream_t st, hipError_t* e)
+{
+    if (act == ACT_SIGMOID)
+        hipLaunchKernelGGL((k_rnet_fwd<HE, HG, ACT_SIGMOID>), dim3(grid), dim3(kBlock), 0, st, th, R, n, E, g, Eu);
+    else
+        hipLaunchKernelGGL((k_rnet_fwd<HE, HG, ACT_TANH>), dim3(grid), dim3(kBlock), 0, st, th, R, n, E, g, Eu);
+    *e = hipGetLastError();
+    return 1;
+}
+
+static int launch_rnet_fwd(int HE, int HG, int act, const float* th, const float* R, int64_t n,
+                           float* E, float* g, float* Eu, int grid, hipStream_t st, hipError_t* e)
+{
+    if (HE == 32 && HG == 10) return launch_rnet_fwd_s<32, 10>(act, th, R, n, E, g, Eu, grid, st, e);
+    if (HE == 16 && HG == 8) return launch_rnet_fwd_s<16, 8>(act, th, R, n, E, g, Eu, grid, st, e);
+    return 0;
+}
+
+template <int HE, int HG>
+static int launch_rnet_bwd_s(int act, const float* th, const float* R, const float* Eb,
+                             const float* gb, int64_t n, float* part, int stride, int grid,
+                             hipStream_t st, hipError_t* e)
+{
+    const size_t shm = 0;
+    if (act == ACT_SIGMOID)
+        hipLaunchKernelGGL((k_rnet_bwd<HE, HG, ACT_SIGMOID>), dim3(grid), dim3(kBlock), shm, st, th, R, Eb, gb, n, part, stride);
+    else
+        hipLaunchKernelGGL((k_rnet_bwd<HE, HG, ACT_TANH>), dim3(grid), dim3(kBlock), shm, st, th, R, Eb, gb, n, part, stride);
+    *e = hipGetLastError();
+    return 1;
+}
+
+static int launch_rnet_bwd(int HE, int HG, int act, const float* th, const float* R, const float* Eb,
+                           const float* gb, int64_t n, float* part, int stride, int grid,
+                           hipStream_t st, hipError_t* e)
+{
+    if (HE == 32 && HG == 10) return launch_rnet_bwd_s<32, 10>(act, th, R, Eb, gb, n, part, stride, grid, st, e);
+    if (HE == 16 && HG == 8) return launch_rnet_bwd_s<16, 8>(act, th, R, Eb, gb, n, part, stride, grid, st, e);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points, pinn_handle** out)
+{
+    if (!out) return PINN_ERR_ARG;
+    *out = nullptr;
+    if (!arch_ok(arch) || max_points < 1 || device < 0) return PINN_ERR_ARG;
+    if (arch->precision != PINN_PREC_F32) return PINN_ERR_UNSUPPORTED;
+    if (!trunk_supported(arch->H, arch->L) || !rnet_supported(arch->HE, arch->HG)) return PINN_ERR_UNSUPPORTED;
+    pinn_handle* h = new (std::nothrow) pinn_handle();
+    if (!h) return PINN_ERR_ARG;
+    memset(h, 0, sizeof *h);
+    h->arch = *arch;
+    h->device = device;
+    h->max_points = max_points;
+    h->PT = trunk_size(arch);
+    h->PR = rnet_size(arch);
+    h->P = h->PT + h->PR;
+    *out = h;
+    HIPCHK(h, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int64_t tiles = (max_points + kBlock - 1) / kBlock;
+    h->nbT = (int)(tiles < (int64_t)cus * 4 ? tiles : (int64_t)cus * 4);
+    h->nbR = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
+    h->strideT = h->PT + 3;
+    h->strideR = h->PR;
+    HIPCHK(h, hipMalloc(&h->E, sizeof(float) * max_points));
+    HIPCHK(h, hipMalloc(&h->g, sizeof(float) * max_points));
+    HIPCHK(h, hipMalloc(&h->Eb, sizeof(float) * max_points));
+    HIPCHK(h, hipMalloc(&h->gb, sizeof(float) * max_points));
+    HIPCHK(h, hipMalloc(&h->partT, sizeof(float) * (size_t)h->nbT * h->strideT));
+    HIPCHK(h, hipMalloc(&h->partR, sizeof(float) * (size_t)h->nbR * h->strideR));
+    HIPCHK(h, hipMalloc(&h->tensor_of, h->P));
+    {
+        int64_t off[64], sz[64];
+        pinn_tensor_layout(arch, off, sz);
+        const int nt = pinn_tensor_count(arch);
+        uint8_t* tmp = new (std::nothrow) uint8_t[h->P];
+        if (!tmp) return fail(h, PINN_ERR_ARG, "out of host memory");
+        for (int t = 0; t < nt; t++)
+            for (int64_t k = off[t]; k < off[t] + sz[t]; k++) tmp[k] = (uint8_t)t;
+        hipError_t e = hipMemcpy(h->tensor_of, tmp, h->P, hipMemcpyHostToDevice);
+        delete[] tmp;
+        if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "hipMemcpy(tensor_of)", e);
+        h->trunk_tensors = ((uint64_t)1 << (2 * (arch->L + 1))) - 1;
+    }
+    snprintf(h->err, sizeof h->err, "ok");
+    return PINN_OK;
+}
+
+static void free_events(pinn_handle* h)
+{
+    if (h->ev) {
+        for (int i = 0; i < 2 * h->prof_slots; i++) (void)hipEventDestroy(h->ev[i]);
+        delete[] h->ev;
+        h->ev = nullptr;
+    }
+    h->prof_slots = 0;
+    h->prof_calls = 0;
+}
+
+extern "C" int pinn_profile_enable(pinn_handle* h, int nslots)
+{
+    if (!h || nslots < 0 || nslots > 1024) return PINN_ERR_ARG;
+    free_events(h);
+    if (nslots == 0) return PINN_OK;
+    h->ev = new (std::nothrow) hipEvent_t[2 * nslots];
+    if (!h->ev) return fail(h, PINN_ERR_ARG, "out of host memory");
+    for (int i = 0; i < 2 * nslots; i++) {
+        hipError_t e = hipEventCreate(&h->ev[i]);
+        if (e != hipSuccess) {
+            for (int k = 0; k < i; k++) (void)hipEventDestroy(h->ev[k]);
+            delete[] h->ev;
+            h->ev = nullptr;
+            return fail(h, PINN_ERR_HIP, "hipEventCreate", e);
+        }
+    }
+    h->prof_slots = nslots;
+    return PINN_OK;
+}
+
+extern "C" int pinn_profile_read(pinn_handle* h, int ncalls, float* mean_ms)
+{
+    if (!h || !mean_ms || ncalls < 1) return PINN_ERR_ARG;
+    if (!h->prof_slots) return fail(h, PINN_ERR_ARG, "profiling is not enabled");
+    if (ncalls > h->prof_slots || ncalls > h->prof_calls)
+        return fail(h, PINN_ERR_ARG, "fewer recorded calls than requested");
+    double sum = 0.0;
+    for (int k = 0; k < ncalls; k++) {
+        const int slot = (int)((h->prof_calls - 1 - k) % h->prof_slots);
+        float ms = 0.f;
+        HIPCHK(h, hipEventSynchronize(h->ev[2 * slot + 1]));
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2 * slot], h->ev[2 * slot + 1]));
+        sum += ms;
+    }
+    *mean_ms = (float)(sum / ncalls);
+    return PINN_OK;
+}
+
+extern "C" int pinn_destroy(pinn_handle* h)
+{
+    if (!h) return PINN_ERR_ARG;
+    free_events(h);
+    (void)hipFree(h->E); (void)hipFree(h->g); (void)hipFree(h->Eb); (void)hipFree(h->gb);
+    (void)hipFree(h->partT); (void)hipFree(h->partR); (void)hipFree(h->tensor_of);
+    delete h;
+    return PINN_OK;
+}
+
+static int check_common(pinn_handle* h, const void* theta, const void* x, const void* y,
+                        const void* z, const void* R, int64_t n, const pinn_ham* ham)
+{
+    if (!h) return PINN_ERR_ARG;
+    if (!theta || !x || !y || !z || !R || !ham || n < 1) return fail(h, PINN_ERR_ARG, "null pointer or n < 1");
+    if (n > h->max_points) return fail(h, PINN_ERR_CAPACITY, "n exceeds max_points");
+    if (ham->Ry != 0.0f || ham->Rz != 0.0f) return fail(h, PINN_ERR_UNSUPPORTED, "Ry/Rz must be 0 (as in the reference)");
+    return PINN_OK;
+}
+
+static int grid_for(int64_t n, int cap)
+{
+    const int64_t tiles = (n + kBlock - 1) / kBlock;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+extern "C" int pinn_forward(pinn_handle* h, const float* theta, const float* x, const float* y,
+                            const float* z, const float* R, int64_t n, const pinn_ham* ham,
+                            float* psi, float* E, float* lap, float* res, void* stream)
+{
+    int rc = check_common(h, theta, x, y, z, R, n, ham);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    const pinn_arch& a = h->arch;
+    if (!launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, R, n, h->E, h->g, E, grid_for(n, h->nbR * 4), st, &e))
+        return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_fwd", e);
+    if (!psi && !lap && !res) return PINN_OK;
+    TrunkArgs A{};
+    A.x = x; A.y = y; A.z = z; A.R = R; A.E = h->E; A.g = h->g; A.mask = nullptr;
+    A.n = n; A.a = ham->a; A.b = ham->b; A.c = ham->c; A.P = ham->P; A.out_scale = a.out_scale;
+    A.invN = 0.f; A.invN1 = 0.f; A.invN2 = 0.f;
+    A.psi = psi; A.lap = lap; A.res = res;
+    const TrunkKey k{a.H, a.L, a.act, a.n_pass, MODE_FWD};
+    if (!launch_trunk(k, theta, A, grid_for(n, h->nbT), st, &e))
+        return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L)");
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_trunk<FWD>", e);
+    return PINN_OK;
+}
+
+extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const float* x,
+                                     const float* y, const float* z, const float* R,
+                                     const uint8_t* mask, int64_t n, const pinn_ham* ham,
+                                     const int64_t* bc_counts, uint64_t trainable_mask,
+                                     float* out, void* stream)
+{
+    int rc = check_common(h, theta, x, y, z, R, n, ham);
+    if (rc) return rc;
+    if (!out) return fail(h, PINN_ERR_ARG, "out is null");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    const pinn_arch& a = h->arch;
+    const int gT = grid_for(n, h->nbT), gR = grid_for(n, h->nbR);
+    if (!launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, R, n, h->E, h->g, nullptr, grid_for(n, h->nbR * 4), st, &e))
+        return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_fwd", e);
+    TrunkArgs A{};
+    A.x = x; A.y = y; A.z = z; A.R = R; A.E = h->E; A.g = h->g; A.mask = mask;
+    A.n = n; A.a = ham->a; A.b = ham->b; A.c = ham->c; A.P = ham->P; A.out_scale = a.out_scale;
+    A.invN = ham->invN; A.invN1 = ham->invN1; A.invN2 = ham->invN2;
+    A.bc_counts = (const long long*)bc_counts;
+    A.Eb = h->Eb; A.gb = h->gb; A.partial = h->partT; A.stride = h->strideT;
+    const bool trunk_trainable = (trainable_mask & h->trunk_tensors) != 0;
+    const TrunkKey k{a.H, a.L, a.act, a.n_pass, trunk_trainable ? MODE_BWD : MODE_HEAD};
+    const int slot = h->prof_slots ? (int)(h->prof_calls % h->prof_slots) : 0;
+    if (h->prof_slots) HIPCHK(h, hipEventRecord(h->ev[2 * slot], st));
+    if (!launch_trunk(k, theta, A, gT, st, &e))
+        return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L)");
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_trunk<BWD>", e);
+    if (h->prof_slots) {
+        HIPCHK(h, hipEventRecord(h->ev[2 * slot + 1], st));
+        h->prof_calls++;
+    }
+    if (!launch_rnet_bwd(a.HE, a.HG, a.act, theta + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st, &e))
+        return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_bwd", e);
+    const int tot = h->P + 3;
+    hipLaunchKernelGGL(k_reduce, dim3((tot + 255) / 256), dim3(256), 0, st, h->partT, gT, h->strideT,
+                       h->PT, h->partR, gR, h->strideR, h->PR, h->tensor_of, trainable_mask, out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_reduce", e);
+    return PINN_OK;
+}
+
+extern "C" int pinn_adam(pinn_handle* h, float* theta, const float* grad, float* m, float* v,
+                         int32_t* step_count, float lr, float beta1, float beta2, float eps,
+                         uint64_t trainable_mask, float* best_theta, float* best_loss, void* stream)
+{
+    if (!h) return PINN_ERR_ARG;
+    if (!theta || !grad || !m || !v || !step_count) return fail(h, PINN_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, (hipStream_t)stream, theta, grad, m, v,
+                       step_count, h->P, lr, beta1, beta2, eps, h->tensor_of, trainable_mask,
+                       best_theta, best_loss);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_adam", e);
+    return PINN_OK;
+}
+
+extern "C" int pinn_sample(pinn_handle* h, uint64_t seed, uint64_t step, int64_t first, int64_t n,
+                           float box, float Rlo, float Rhi, float cutoff, float bc_cutoff, float* x,
+                           float* y, float* z, float* R, uint8_t* mask, int64_t* counts, void* stream)
+{
+    if (!h) return PINN_ERR_ARG;
+    if (!x || !y || !z || !R || n < 1 || first < 0) return fail(h, PINN_ERR_ARG, "null pointer or bad range");
+    hipStream_t st = (hipStream_t)stream;
+    if (counts) HIPCHK(h, hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), st));
+    hipLaunchKernelGGL(k_sample, dim3(grid_for(n, 2048)), dim3(kBlock), 0, st, seed, step, first, n,
+                       box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
+                       (unsigned long long*)counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_sample", e);
+    return PINN_OK;
+}

@@ -1,0 +1,54 @@
+"""Data-parallel plan for the collocation batch.
+
+Points are i.i.d., the loss is a mean over points, so the path shards naturally:
+rank r draws points [r*n_local, (r+1)*n_local) of the global Philox stream and
+there are exactly two exchange steps per training step, both tiny SUM all-reduces:
+  * BC set sizes (int64[2]) after sampling, so every rank weights its boundary
+    points with the GLOBAL 1/N_bc1, 1/N_bc2;
+  * one flat fp32 buffer [grad(P) | Lpde, Lbc1, Lbc2] after the fused kernel
+    (already scaled with global 1/N), after which every rank runs the same Adam.
+The backend is whatever torch.distributed was initialised with ("nccl" = RCCL over
+xGMI on MI355X; "gloo" in the CPU tests).  With world_size 1 nothing is called.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallelPlan:
+    def __init__(self, n_local, rank=None, world=None, group=None):
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if world > 1 else 0
+        self.n_local, self.rank, self.world, self.group = int(n_local), int(rank), int(world), group
+
+    @property
+    def first(self):
+        """offset of this rank's shard in the global point stream"""
+        return self.rank * self.n_local
+
+    @property
+    def n_global(self):
+        return self.n_local * self.world
+
+    @property
+    def invN(self):
+        return 1.0 / self.n_global
+
+    def reduce_counts(self, counts):
+        """int64[2] BC set sizes: local -> global (in place)."""
+        if self.world > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+        return counts
+
+    def reduce_grad(self, buf):
+        """fp32[P+3] = [grad | three loss terms]: local partial -> global (in place)."""
+        if self.world > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return buf
+
+    def max_over_ranks(self, seconds, device):
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())

@@ -124,9 +124,11 @@ int pinn_residual_fwd_bwd(pinn_handle *h, const float *theta, const float *x, co
  * amsgrad, weight_decay 0) fused with train.py:58-60 best-so-far tracking:
  * if Ltot = grad[P]+grad[P+1]+grad[P+2] < *best_loss, theta (pre-update) is
  * copied to best_theta and *best_loss updated (both may be NULL).  step_count
- * (device int32[1]) is incremented first and used for the bias correction. */
+ * (device int32[1]) is incremented first and used for the bias correction.
+ * The hyper-parameters are doubles: like torch, the scalars 1-beta, lr/(1-beta1^t),
+ * sqrt(1-beta2^t) are formed in double and rounded to fp32 once. */
 int pinn_adam(pinn_handle *h, float *theta, const float *grad, float *m, float *v,
-              int32_t *step_count, float lr, float beta1, float beta2, float eps,
+              int32_t *step_count, double lr, double beta1, double beta2, double eps,
               uint64_t trainable_mask, float *best_theta, float *best_loss, void *stream);
 
 /* ---- measurement --------------------------------------------------------- */

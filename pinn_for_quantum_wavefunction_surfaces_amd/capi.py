@@ -66,7 +66,7 @@ def load_library():
     lib.pinn_forward.argtypes = [vp] + [fp] * 5 + [C.c_int64, C.POINTER(Ham)] + [fp] * 4 + [vp]
     lib.pinn_residual_fwd_bwd.argtypes = [vp] + [fp] * 5 + [vp, C.c_int64, C.POINTER(Ham), i64p,
                                                              C.c_uint64, fp, vp]
-    lib.pinn_adam.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_float] * 4 + [C.c_uint64, fp, fp, vp]
+    lib.pinn_adam.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_double] * 4 + [C.c_uint64, fp, fp, vp]
     lib.pinn_profile_enable.argtypes = [vp, C.c_int]
     lib.pinn_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     _lib = lib

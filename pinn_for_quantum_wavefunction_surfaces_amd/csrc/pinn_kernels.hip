@@ -552,32 +552,50 @@ __global__ __launch_bounds__(kBlock) void k_rnet_bwd(const float* __restrict__ t
 }
 
 // --------------------------------------------------------- reduce / Adam / sample
-// out[e] = sum_b partial[b][e] in fixed order; frozen tensors -> 0
-__global__ void k_reduce(const float* __restrict__ partT, int nbT, int strideT, int PT,
-                         const float* __restrict__ partR, int nbR, int strideR, int PR,
-                         const uint8_t* __restrict__ tensor_of, uint64_t trainable_mask,
-                         float* __restrict__ out)
+// out[e] = sum_b partial[b][e]; frozen tensors -> 0.  Block = 64 entries x 16 row groups:
+// thread (tx, ty) sums rows ty, ty+16, ... of column e (coalesced over tx, 8 loads in
+// flight), then the 16 group sums are added in fixed order: bitwise reproducible.
+__global__ __launch_bounds__(1024) void k_reduce(const float* __restrict__ partT, int nbT, int strideT, int PT,
+                                                 const float* __restrict__ partR, int nbR, int strideR, int PR,
+                                                 const uint8_t* __restrict__ tensor_of, uint64_t trainable_mask,
+                                                 float* __restrict__ out)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float sh[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
     const int P = PT + PR;
-    if (e >= P + 3) return;
     float s = 0.f;
-    if (e < PT) {
-        for (int b = 0; b < nbT; b++) s += partT[(size_t)b * strideT + e];
-    } else if (e < P) {
-        for (int b = 0; b < nbR; b++) s += partR[(size_t)b * strideR + (e - PT)];
-    } else {
-        for (int b = 0; b < nbT; b++) s += partT[(size_t)b * strideT + PT + (e - P)];
+    if (e < P + 3) {
+        const float* src;
+        int nb, stride;
+        if (e < PT) { src = partT + e; nb = nbT; stride = strideT; }
+        else if (e < P) { src = partR + (e - PT); nb = nbR; stride = strideR; }
+        else { src = partT + PT + (e - P); nb = nbT; stride = strideT; }
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = ty;
+        for (; b + 16 * 7 < nb; b += 16 * 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] += src[(size_t)(b + 16 * k) * stride];
+        }
+        for (; b < nb; b += 16) a[0] += src[(size_t)b * stride];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
-    if (e < P && !((trainable_mask >> tensor_of[e]) & 1)) s = 0.f;
-    out[e] = s;
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < P + 3) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += sh[k][tx];
+        if (e < P && !((trainable_mask >> tensor_of[e]) & 1)) t = 0.f;
+        out[e] = t;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
                                                const float* __restrict__ grad,
                                                float* __restrict__ m, float* __restrict__ v,
-                                               int32_t* __restrict__ step_count, int P, float lr,
-                                               float b1, float b2, float eps,
+                                               int32_t* __restrict__ step_count, int P, double lr,
+                                               double b1d, double b2d, double epsd,
                                                const uint8_t* __restrict__ tensor_of,
                                                uint64_t trainable_mask,
                                                float* __restrict__ best_theta,
@@ -586,18 +604,21 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
     const int step = *step_count + 1;
     const float ltot = grad[P] + grad[P + 1] + grad[P + 2];
     const bool better = best_loss != nullptr && ltot < *best_loss;
-    const double bc1 = 1.0 - pow((double)b1, (double)step);
-    const double bc2 = 1.0 - pow((double)b2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
+    // scalars are formed in double and rounded once, as torch does for fp32 tensors
+    const double bc1 = 1.0 - pow(b1d, (double)step);
+    const double bc2 = 1.0 - pow(b2d, (double)step);
+    const float step_size = (float)(lr / bc1);
     const float inv_bc2s = (float)(1.0 / sqrt(bc2));
+    const float b1 = (float)b1d, b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
+    const float eps = (float)epsd;
     __syncthreads();  // every thread has read step_count / best_loss
     for (int k = threadIdx.x; k < P; k += blockDim.x) {
         const float th = theta[k];
         if (better && best_theta) best_theta[k] = th;  // train.py:58-60: params the loss was taken at
         if (!((trainable_mask >> tensor_of[k]) & 1)) continue;
         const float g = grad[k];
-        const float mk = b1 * m[k] + (1.0f - b1) * g;
-        const float vk = b2 * v[k] + (1.0f - b2) * g * g;
+        const float mk = b1 * m[k] + omb1 * g;
+        const float vk = b2 * v[k] + omb2 * g * g;
         m[k] = mk;
         v[k] = vk;
         const float denom = sqrtf(vk) * inv_bc2s + eps;
@@ -876,7 +897,7 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int64_t tiles = (max_points + kBlock - 1) / kBlock;
-    h->nbT = (int)(tiles < (int64_t)cus * 4 ? tiles : (int64_t)cus * 4);
+    h->nbT = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
     h->nbR = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
     h->strideT = h->PT + 3;
     h->strideR = h->PR;
@@ -1041,7 +1062,7 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_bwd", e);
     const int tot = h->P + 3;
-    hipLaunchKernelGGL(k_reduce, dim3((tot + 255) / 256), dim3(256), 0, st, h->partT, gT, h->strideT,
+    hipLaunchKernelGGL(k_reduce, dim3((tot + 63) / 64), dim3(1024), 0, st, h->partT, gT, h->strideT,
                        h->PT, h->partR, gR, h->strideR, h->PR, h->tensor_of, trainable_mask, out);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_reduce", e);
@@ -1049,7 +1070,7 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
 }
 
 extern "C" int pinn_adam(pinn_handle* h, float* theta, const float* grad, float* m, float* v,
-                         int32_t* step_count, float lr, float beta1, float beta2, float eps,
+                         int32_t* step_count, double lr, double beta1, double beta2, double eps,
                          uint64_t trainable_mask, float* best_theta, float* best_loss, void* stream)
 {
     if (!h) return PINN_ERR_ARG;
@@ -1070,7 +1091,7 @@ extern "C" int pinn_sample(pinn_handle* h, uint64_t seed, uint64_t step, int64_t
     if (!x || !y || !z || !R || n < 1 || first < 0) return fail(h, PINN_ERR_ARG, "null pointer or bad range");
     hipStream_t st = (hipStream_t)stream;
     if (counts) HIPCHK(h, hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), st));
-    hipLaunchKernelGGL(k_sample, dim3(grid_for(n, 2048)), dim3(kBlock), 0, st, seed, step, first, n,
+    hipLaunchKernelGGL(k_sample, dim3(grid_for(n, 512)), dim3(kBlock), 0, st, seed, step, first, n,
                        box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
                        (unsigned long long*)counts);
     hipError_t e = hipGetLastError();

@@ -31,6 +31,22 @@ def total_flops_per_point(H, L, HE, HG, n_pass):
     return trunk_flops_per_point(H, L, n_pass) + 2.0 * (3 * (HE * HE + 2 * HE) + 6 * HG)
 
 
+# workloads.  "ref16": the reference network (poc/main.py:225-245) on the fp32 parity path with
+# the published ionHsym weights.  "wide64": the 2x64 tanh trunk named in BASELINE.json's configs,
+# NN_ion formulation (symmetric double pass), bf16 MFMA trunk, seeded nn.Linear-style init.
+ARCHS = {
+    "ref16": dict(H=16, L=2, HE=32, HG=10, act=0, n_pass=2, out_scale=1.0, precision="f32",
+                  act_name="sigmoid", peak=157.3, dtype="f32",
+                  label="reference arch 2x16 trunk + 2x32 E-net + 1x10 gate, sigmoid, fp32 "
+                        "(VALU + f32 MFMA), ionHsym weights"),
+    "wide64": dict(H=64, L=2, HE=32, HG=10, act=1, n_pass=2, out_scale=1.0, precision="bf16",
+                   act_name="tanh", peak=2500.0, dtype="bf16",
+                   label="2x64 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "
+                         "accumulate, seeded random init"),
+}
+DEFAULT_ARCH = "wide64"
+
+
 def cpu_baseline(theta_np, arch, budget_s=12.0):
     """Reference formulation (nested autograd.grad, Adam) in PyTorch on the host cores."""
     from oracle import torch_baseline as TB
@@ -73,6 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=1000000, help="points per GPU per step")
+    ap.add_argument("--arch", choices=sorted(ARCHS), default=DEFAULT_ARCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -91,10 +108,14 @@ def main():
 
     import pinn_for_quantum_wavefunction_surfaces_amd as pkg
     params = pkg.set_params()
-    arch = dict(H=16, L=2, HE=32, HG=10, act=0, n_pass=2, out_scale=1.0)
-    w = np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))
-    model = pkg.NN_ion(params).to(dev)
-    model.load_flat_params(torch.tensor(w["ionHsym"]))      # random-init class weights would do too
+    arch = ARCHS[args.arch]
+    torch.manual_seed(12345)
+    model = pkg.NN_ion(params, arch["H"], arch["HE"], arch["HG"], n_hidden=arch["L"],
+                       act=arch["act_name"], precision=arch["precision"]).to(dev)
+    if args.arch == "ref16":
+        w = np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))
+        model.load_flat_params(torch.tensor(w["ionHsym"]))
+    theta0 = model.flat_params(dtype=torch.float64).cpu().numpy()
     plan = pkg.DataParallelPlan(args.points, rank=rank, world=world)
     tr = pkg.Trainer(model, params, n_points=args.points, lr=8e-3, seed=12345, device=dev, plan=plan)
     tr.h.profile_enable(min(max(args.steps, 1), 1024))
@@ -120,7 +141,7 @@ def main():
         n_total = args.points * world
         fl_trunk = trunk_flops_per_point(arch["H"], arch["L"], arch["n_pass"])
         achieved = fl_trunk * args.points / (trunk_ms * 1e-3) / 1e12
-        peak = 157.3
+        peak = arch["peak"]
         out = {
             "metric": "PDE-residual collocation points/sec (H2+ ion, batch 1M)",
             "value": n_total * args.steps / dt,
@@ -132,21 +153,23 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": arch["dtype"],
             "data": "synthetic",
-            "config": {"workload": "H2+ ion symmetric (NN_ion), %d points/step/GPU, reference "
-                                   "arch 2x16 trunk + 2x32 E-net + 1x10 gate sigmoid, fp32, "
-                                   "fused Laplacian kernel" % args.points,
+            "config": {"workload": "H2+ ion symmetric (NN_ion), %d points/step/GPU, %s, fused "
+                                   "Laplacian kernel" % (args.points, arch["label"]),
+                       "arch": args.arch,
                        "points_per_gpu": args.points, "global_batch": n_total,
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None, "kernel": "k_trunk",
+                         "frac": achieved / peak, "traffic": None, "kernel": "k_trunk" if arch["dtype"] == "f32" else "k_trunk_mfma",
                          "kernel_ms": trunk_ms, "flops_per_point": fl_trunk,
-                         "note": "fp32 path: vector and f32-matrix peaks are both 157.3 TFLOP/s"},
+                         "note": ("fp32 path: vector and f32-matrix peaks are both 157.3 TFLOP/s"
+                                  if arch["dtype"] == "f32" else
+                                  "bf16 dense MFMA peak; algorithmic trunk flops only")},
             "loss": {"Ltot": Ltot, "Lpde": Lpde, "Lbc": Lbc},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w["ionHsym"], arch)
+            out["cpu_baseline"] = cpu_baseline(theta0, arch)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

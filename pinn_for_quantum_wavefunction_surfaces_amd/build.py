@@ -10,19 +10,19 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libpinn_hip.so")
-SOURCES = ["pinn_kernels.hip"]
-HEADERS = ["pinn_math.h", os.path.join("..", "..", "include", "pinn.h")]
-# -fno-slp-vectorize: the SLP pass packs scalar FMAs into v_pk_* and then has to copy
-# the SGPR-resident weights into VGPR pairs first (+40 % VALU instructions).
-FLAGS = ["-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-         "-Wno-unused-value"]
+# per-source extra flags.  pinn_kernels.hip: -fno-slp-vectorize, because the SLP pass packs
+# scalar FMAs into v_pk_* and then has to copy the SGPR-resident weights into VGPR pairs
+# first (+40 % VALU instructions).  The MFMA trunk keeps SLP (its operands are VGPR vectors).
+SOURCES = {"pinn_kernels.hip": ["-fno-slp-vectorize"], "pinn_trunk_mfma.hip": []}
+HEADERS = ["pinn_math.h", "pinn_common.h", os.path.join("..", "..", "include", "pinn.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
 def _stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in list(SOURCES) + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -33,7 +33,23 @@ def build_hip(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found; cannot build %s" % SO)
-    cmd = [hipcc] + FLAGS + ["-o", SO] + [os.path.join(CSRC, s) for s in SOURCES]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
+    for src, extra in SOURCES.items():
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(
+                os.path.getmtime(os.path.join(CSRC, d)) for d in [src] + HEADERS):
+            continue
+        cmd = [hipcc] + FLAGS + extra + ["-c", "-o", obj, os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -1,0 +1,33 @@
+// pinn_common.h -- declarations shared by the translation units of libpinn_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;             // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HEAD = 2 };
+
+struct TrunkArgs {
+    const float *x, *y, *z, *R;
+    const float *E, *g;       // from k_rnet_fwd
+    const uint8_t* mask;      // may be null
+    int64_t n;
+    float a, b, c, P, out_scale, invN, invN1, invN2;
+    const long long* bc_counts;  // optional device int64[2]: overrides invN1/invN2
+    float *psi, *lap, *res;   // MODE_FWD outputs (nullable)
+    float *Eb, *gb;           // MODE_BWD / MODE_HEAD per-point adjoints
+    float* partial;           // [gridDim.x][stride]: trunk grads then 3 loss terms
+    int stride;
+};
+
+// ---- MFMA trunk (pinn_trunk_mfma.hip): bf16 operands, fp32 accumulate --------------------
+// packed bf16 weights for one call: [(L-1)][2 (fwd, bwd)][H*H] (see pack order there)
+size_t mfma_packed_weight_bytes(int H, int L);
+bool mfma_trunk_supported(int H, int L);
+int mfma_partial_stride(int H, int L);   // floats per block partial row (trunk grads + 3)
+// enqueue pack + trunk kernel; returns false when (H, L, act, npass, mode) has no instantiation
+bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, const float* theta,
+                       void* packed_weights, const TrunkArgs& A, int grid, hipStream_t st,
+                       hipError_t* err);

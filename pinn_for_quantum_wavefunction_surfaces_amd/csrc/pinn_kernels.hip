@@ -29,6 +29,7 @@
 
 #include "../../include/pinn.h"
 #include "pinn_math.h"
+#include "pinn_common.h"
 
 using namespace pinn;
 
@@ -36,12 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kWave = 64;
-constexpr int kBlock = 256;             // 4 waves
-constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kPitch = 68;              // floats per staged row: 64 points + 4 pad (272 B, 16-B aligned)
-
-enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HEAD = 2 };
 
 // ---------------------------------------------------------------- wave tiles
 // D[16x16] += sum over the wave's 64 points of U[j][pt] * V[i][pt].
@@ -248,18 +244,6 @@ struct TrunkSink {
     }
 };
 
-struct TrunkArgs {
-    const float *x, *y, *z, *R;
-    const float *E, *g;       // from k_rnet_fwd
-    const uint8_t* mask;      // may be null
-    int64_t n;
-    float a, b, c, P, out_scale, invN, invN1, invN2;
-    const long long* bc_counts;  // optional device int64[2]: overrides invN1/invN2
-    float *psi, *lap, *res;   // MODE_FWD outputs (nullable)
-    float *Eb, *gb;           // MODE_BWD / MODE_HEAD per-point adjoints
-    float* partial;           // [gridDim.x][stride]: trunk grads then 3 loss terms
-    int stride;
-};
 
 template <int H, int L, int ACT, int NPASS, int MODE>
 __global__ __launch_bounds__(kBlock, 2) void k_trunk(const float* __restrict__ th, TrunkArgs A)
@@ -717,6 +701,7 @@ struct pinn_handle {
     int strideT, strideR;
     float *E, *g, *Eb, *gb; // per-point scratch
     float *partT, *partR;   // per-block partials
+    void* wpk;              // packed bf16 weights (MFMA path)
     uint8_t* tensor_of;     // [P] tensor index of each parameter
     uint64_t trunk_tensors; // bits of the trunk tensors
     int prof_slots;          // 0 = off
@@ -875,13 +860,30 @@ static int launch_rnet_bwd(int HE, int HG, int act, const float* th, const float
 
 }  // namespace
 
+static int run_trunk(pinn_handle* h, int mode, const float* theta, const TrunkArgs& A, int grid,
+                     hipStream_t st, hipError_t* e)
+{
+    const pinn_arch& a = h->arch;
+    if (a.precision == PINN_PREC_F32) {
+        const TrunkKey k{a.H, a.L, a.act, a.n_pass, mode};
+        return launch_trunk(k, theta, A, grid, st, e);
+    }
+    return launch_trunk_mfma(a.H, a.L, a.act, a.n_pass, mode, theta, h->wpk, A, grid, st, e) ? 1 : 0;
+}
+
 extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points, pinn_handle** out)
 {
     if (!out) return PINN_ERR_ARG;
     *out = nullptr;
     if (!arch_ok(arch) || max_points < 1 || device < 0) return PINN_ERR_ARG;
-    if (arch->precision != PINN_PREC_F32) return PINN_ERR_UNSUPPORTED;
-    if (!trunk_supported(arch->H, arch->L) || !rnet_supported(arch->HE, arch->HG)) return PINN_ERR_UNSUPPORTED;
+    if (arch->precision == PINN_PREC_F32) {
+        if (!trunk_supported(arch->H, arch->L)) return PINN_ERR_UNSUPPORTED;
+    } else if (arch->precision == PINN_PREC_BF16) {
+        if (!mfma_trunk_supported(arch->H, arch->L)) return PINN_ERR_UNSUPPORTED;
+    } else {
+        return PINN_ERR_UNSUPPORTED;
+    }
+    if (!rnet_supported(arch->HE, arch->HG)) return PINN_ERR_UNSUPPORTED;
     pinn_handle* h = new (std::nothrow) pinn_handle();
     if (!h) return PINN_ERR_ARG;
     memset(h, 0, sizeof *h);
@@ -897,7 +899,9 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int64_t tiles = (max_points + kBlock - 1) / kBlock;
-    h->nbT = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
+    // resident blocks per CU: 2 for the fp32 VALU trunk (2 waves/SIMD), 1 for the MFMA trunk
+    const int per_cu = arch->precision == PINN_PREC_F32 ? 2 : 1;
+    h->nbT = (int)(tiles < (int64_t)cus * per_cu ? tiles : (int64_t)cus * per_cu);
     h->nbR = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
     h->strideT = h->PT + 3;
     h->strideR = h->PR;
@@ -908,6 +912,8 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     HIPCHK(h, hipMalloc(&h->partT, sizeof(float) * (size_t)h->nbT * h->strideT));
     HIPCHK(h, hipMalloc(&h->partR, sizeof(float) * (size_t)h->nbR * h->strideR));
     HIPCHK(h, hipMalloc(&h->tensor_of, h->P));
+    if (arch->precision != PINN_PREC_F32)
+        HIPCHK(h, hipMalloc(&h->wpk, mfma_packed_weight_bytes(arch->H, arch->L)));
     {
         int64_t off[64], sz[64];
         pinn_tensor_layout(arch, off, sz);
@@ -980,6 +986,7 @@ extern "C" int pinn_destroy(pinn_handle* h)
     free_events(h);
     (void)hipFree(h->E); (void)hipFree(h->g); (void)hipFree(h->Eb); (void)hipFree(h->gb);
     (void)hipFree(h->partT); (void)hipFree(h->partR); (void)hipFree(h->tensor_of);
+    if (h->wpk) (void)hipFree(h->wpk);
     delete h;
     return PINN_OK;
 }
@@ -1018,9 +1025,8 @@ extern "C" int pinn_forward(pinn_handle* h, const float* theta, const float* x, 
     A.n = n; A.a = ham->a; A.b = ham->b; A.c = ham->c; A.P = ham->P; A.out_scale = a.out_scale;
     A.invN = 0.f; A.invN1 = 0.f; A.invN2 = 0.f;
     A.psi = psi; A.lap = lap; A.res = res;
-    const TrunkKey k{a.H, a.L, a.act, a.n_pass, MODE_FWD};
-    if (!launch_trunk(k, theta, A, grid_for(n, h->nbT), st, &e))
-        return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L)");
+    if (!run_trunk(h, MODE_FWD, theta, A, grid_for(n, h->nbT), st, &e))
+        return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L, precision)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_trunk<FWD>", e);
     return PINN_OK;
 }
@@ -1048,11 +1054,10 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     A.bc_counts = (const long long*)bc_counts;
     A.Eb = h->Eb; A.gb = h->gb; A.partial = h->partT; A.stride = h->strideT;
     const bool trunk_trainable = (trainable_mask & h->trunk_tensors) != 0;
-    const TrunkKey k{a.H, a.L, a.act, a.n_pass, trunk_trainable ? MODE_BWD : MODE_HEAD};
     const int slot = h->prof_slots ? (int)(h->prof_calls % h->prof_slots) : 0;
     if (h->prof_slots) HIPCHK(h, hipEventRecord(h->ev[2 * slot], st));
-    if (!launch_trunk(k, theta, A, gT, st, &e))
-        return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L)");
+    if (!run_trunk(h, trunk_trainable ? MODE_BWD : MODE_HEAD, theta, A, gT, st, &e))
+        return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L, precision, mode)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_trunk<BWD>", e);
     if (h->prof_slots) {
         HIPCHK(h, hipEventRecord(h->ev[2 * slot + 1], st));

@@ -1,0 +1,622 @@
+// pinn_trunk_mfma.hip -- fused trunk kernel for wide architectures on the bf16 matrix cores.
+//
+// Same mathematics as k_trunk in pinn_kernels.hip (five streams per neuron, hand-derived
+// adjoint; train.py:41-57,71 / poc/main.py:247-303,341-355,403), different execution shape:
+// at H >= 64 the H x H layers are dense GEMMs, so they run on v_mfma_f32_16x16x32_bf16.
+//
+// Shape ("transposed, point-split"):
+//   * a workgroup is 4 waves; each wave owns 16 points per tile and ALL H neurons.
+//   * every GEMM is computed transposed, D[neuron][column] with column = (stream, point):
+//     the five streams of one point are five 16-column tiles, so lane (g = lane>>4,
+//     c = lane&15) holds, for point c, the neurons 16*jt + 4*g + r (r = 0..3) of every row
+//     tile jt and all five streams of them in its own registers: activation and adjoint
+//     algebra are purely lane-local.
+//   * the accumulator layout of one layer IS the B-operand layout of the next (and of the
+//     reverse pass): a lane's 8 bf16 of a k-chunk are its 4 neurons of row tiles 2kc and
+//     2kc+1.  That fixes a permutation of the contraction index, applied once to the
+//     weights when they are packed (k_pack_weights), so activations never leave registers
+//     between layers: no LDS round trip, no shuffles.
+//   * weights (A operands) are staged once per block in LDS in fragment order (lane-linear
+//     16-byte reads); forward uses W, the input-adjoint GEMM uses W^T (second packed copy).
+//   * the weight gradient contracts over columns (points), i.e. across lanes.  Each wave
+//     writes (adjoint, input) B-fragments as rows of a small [column][neuron] LDS image and
+//     reads them back transposed with ds_read_b64_tr_b16 as MFMA operands; gradient tiles
+//     accumulate in registers for the whole kernel.  Vector gradients (biases, w_out, the
+//     2-column first layer) are lane-local running sums, reduced once at the end.
+//   * per-block partials, fixed-order second stage (k_reduce): bitwise reproducible.
+//
+// Precision: bf16 MFMA operands (activations, adjoints, weights), fp32 accumulation and
+// fp32 elementwise math; saved pre-activations are kept as bf16.  Tolerances are stated in
+// tests/test_gpu_parity.py; this path is NOT the 1e-5 parity path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pinn_math.h"
+#include "pinn_common.h"
+
+using namespace pinn;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+// position of neuron slot (kc, g, j) of a B fragment: lane group g holds, as element j of
+// k-chunk kc, neuron 32kc + 16(j>>2) + 4g + (j&3)  (= row tile 2kc + (j>>2), register j&3)
+__host__ __device__ constexpr int slot_neuron(int kc, int g, int j)
+{
+    return 32 * kc + 16 * (j >> 2) + 4 * g + (j & 3);
+}
+// image / gradient-tile order q = 32kc + 8g + j  ->  neuron
+__host__ __device__ constexpr int q_neuron(int q) { return slot_neuron(q >> 5, (q >> 3) & 3, q & 7); }
+
+template <int H, int L>
+struct MCfg {
+    static constexpr int HT = H / 16;       // row tiles
+    static constexpr int KC = H / 32;       // k-chunks of 32
+    static constexpr int NW = L - 1;        // H x H layers
+    static constexpr int PITCH = H + 8;     // bf16 elements per image row (16-B aligned, skews banks)
+    static constexpr int IMG = 32 * PITCH;  // one image: 32 columns (2 streams x 16 points)
+    static constexpr int WPK = NW * 2 * H * H;                 // packed bf16 weights
+    static constexpr int NSMALL = 3 * H + NW * H + H + 4;      // W0(2H) b0(H) b_l wout bout
+    static constexpr size_t LDS_BYTES = (size_t)WPK * 2 + NSMALL * 4 + kWavesPerBlock * 2 * IMG * 2;
+};
+
+// ------------------------------------------------------------------ weight pack
+// fwd: element j of lane (g, row) of fragment (jt, kc) = W[16jt + row][slot_neuron(kc, g, j)]
+// bwd: ...                                            = W[slot_neuron(kc, g, j)][16it + row]
+template <int H, int L>
+__global__ void k_pack_weights(const float* __restrict__ theta, __bf16* __restrict__ out)
+{
+    using C = MCfg<H, L>;
+    using Lay = TrunkLayout<H, L>;
+    const int per = C::HT * C::KC * 64;  // 16-byte fragments-of-lane per (layer, dir)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= C::NW * 2 * per) return;
+    const int l = t / (2 * per) + 1, rem = t % (2 * per), dir = rem / per, f = rem % per;
+    const int lane = f & 63, kc = (f >> 6) % C::KC, tt = (f >> 6) / C::KC;
+    const int g = lane >> 4, row = lane & 15;
+    const float* W = theta + Lay::W(l);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int kn = slot_neuron(kc, g, j);
+        const float w = dir == 0 ? W[(16 * tt + row) * H + kn] : W[kn * H + 16 * tt + row];
+        v[j] = (__bf16)w;
+    }
+    *reinterpret_cast<bf16x8*>(out + ((size_t)((l - 1) * 2 + dir) * H * H) + (size_t)f * 8) = v;
+}
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ f32x4 splat(float v) { return f32x4{v, v, v, v}; }
+
+__device__ __forceinline__ u32x2 pack4(f32x4 v)  // 4 fp32 -> 4 bf16 (round to nearest even)
+{
+    bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    return __builtin_bit_cast(u32x2, b);
+}
+
+__device__ __forceinline__ f32x4 unpack4(u32x2 p)
+{
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, p[0] << 16);
+    r[1] = __builtin_bit_cast(float, p[0] & 0xffff0000u);
+    r[2] = __builtin_bit_cast(float, p[1] << 16);
+    r[3] = __builtin_bit_cast(float, p[1] & 0xffff0000u);
+    return r;
+}
+
+template <int ACT>
+__device__ __forceinline__ void act012v(f32x4 a, f32x4& s, f32x4& s1, f32x4& s2)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float x, y, z;
+        act012<ACT, float>(a[r], x, y, z);
+        s[r] = x; s1[r] = y; s2[r] = z;
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ void act123v(f32x4 s, f32x4& s1, f32x4& s2, f32x4& s3)
+{
+    if (ACT == ACT_SIGMOID) {
+        s1 = s - s * s;
+        s2 = s1 - 2.0f * s * s1;
+        s3 = s1 - 6.0f * s1 * s1;
+    } else {
+        s1 = 1.0f - s * s;
+        s2 = -2.0f * s * s1;
+        s3 = s1 * (4.0f - 6.0f * s1);
+    }
+}
+
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float xg_sum(float v)  // sum over the 4 lane groups of one point
+{
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ float row16_sum(float v)  // sum over the 16 points of a lane group
+{
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ the kernel
+template <int H, int L, int ACT, int NPASS, int MODE>
+__global__ __launch_bounds__(kBlock, 1) void k_trunk_mfma(const float* __restrict__ theta,
+                                                          const __bf16* __restrict__ wpk_g,
+                                                          TrunkArgs A)
+{
+    using C = MCfg<H, L>;
+    using Lay = TrunkLayout<H, L>;
+    constexpr int HT = C::HT, KC = C::KC, NW = C::NW, PITCH = C::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* wpk = reinterpret_cast<__bf16*>(lds_raw);
+    float* small = reinterpret_cast<float*>(lds_raw + (size_t)C::WPK * 2);
+    __bf16* imgs = reinterpret_cast<__bf16*>(lds_raw + (size_t)C::WPK * 2 + C::NSMALL * 4);
+    // small: [0,2H) W0 ; [2H,3H) b0 ; [3H + (l-1)H) b_l ; then wout[H] ; bout
+    float* sW0 = small;
+    float* sb0 = small + 2 * H;
+    float* sbl = small + 3 * H;
+    float* swo = small + 3 * H + NW * H;
+    float* sbo = swo + H;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    __bf16* imgY = imgs + (size_t)wave * 2 * C::IMG;
+    __bf16* imgX = imgY + C::IMG;
+
+    // ---- stage weights (bf16, fragment order) and the small fp32 parameters in LDS
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(wpk_g);
+        uint4* dst = reinterpret_cast<uint4*>(wpk);
+        for (int k = threadIdx.x; k < C::WPK / 8; k += kBlock) dst[k] = src[k];
+        for (int k = threadIdx.x; k < 2 * H; k += kBlock) sW0[k] = theta[Lay::W(0) + k];
+        for (int k = threadIdx.x; k < H; k += kBlock) {
+            sb0[k] = theta[Lay::b(0) + k];
+            swo[k] = theta[Lay::Wout + k];
+#pragma unroll
+            for (int l = 1; l < L; l++) sbl[(l - 1) * H + k] = theta[Lay::b(l) + k];
+        }
+        if (threadIdx.x == 0) sbo[0] = theta[Lay::bout];
+        for (int k = lane; k < 2 * C::IMG / 2; k += 64) reinterpret_cast<unsigned*>(imgY)[k] = 0u;
+    }
+    __syncthreads();
+
+    // ---- persistent gradient state
+    f32x4 wacc[NW][HT][HT];   // W_l-bar tiles in q-order (see q_neuron)
+    f32x4 bacc[L][HT];        // b_l-bar, lane-local running sums (this lane's neurons, its point column)
+    f32x4 w0acc[HT][2];       // W_0-bar[:, 0..1]
+    f32x4 woacc[HT];          // wout-bar
+    float acc_bout = 0.f, acc_pde = 0.f, acc_bc1 = 0.f, acc_bc2 = 0.f;
+    if (MODE == MODE_BWD) {
+#pragma unroll
+        for (int l = 0; l < NW; l++)
+#pragma unroll
+            for (int a = 0; a < HT; a++)
+#pragma unroll
+                for (int b = 0; b < HT; b++) wacc[l][a][b] = splat(0.f);
+#pragma unroll
+        for (int l = 0; l < L; l++)
+#pragma unroll
+            for (int a = 0; a < HT; a++) bacc[l][a] = splat(0.f);
+#pragma unroll
+        for (int a = 0; a < HT; a++) { w0acc[a][0] = splat(0.f); w0acc[a][1] = splat(0.f); woacc[a] = splat(0.f); }
+    }
+    float invN1 = A.invN1, invN2 = A.invN2;
+    if (MODE != MODE_FWD && A.bc_counts) {
+        const long long c1 = A.bc_counts[0], c2 = A.bc_counts[1];
+        invN1 = c1 > 0 ? 1.0f / (float)c1 : 0.0f;
+        invN2 = c2 > 0 ? 1.0f / (float)c2 : 0.0f;
+    }
+    const float lead = g == 0 ? 1.0f : 0.0f;  // one lane group per point feeds the per-point sums
+    const int64_t ntile = (A.n + 15) / 16;
+
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntile;
+         tile += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t idx = tile * 16 + c;
+        const bool valid = idx < A.n;
+        const int64_t id = valid ? idx : A.n - 1;
+        const float xv = A.x[id], yv = A.y[id], zv = A.z[id], Rv = A.R[id];
+        const float Ev = A.E[id], gv = A.g[id];
+        float m1 = 0.f, m2 = 0.f;
+        if (MODE != MODE_FWD && A.mask) {
+            const uint8_t mk = A.mask[id];
+            m1 = float(mk & 1);
+            m2 = float((mk >> 1) & 1);
+        }
+        float inA[2][5], ri1, ri2;
+        orbital<float>(xv - Rv, yv, zv, inA[0], ri1);
+        orbital<float>(xv + Rv, yv, zv, inA[1], ri2);
+        const float F = inA[0][0] + A.P * inA[1][0];
+        const float lapF = inA[0][4] + A.P * inA[1][4];
+
+        Tail<float> t;
+        float SvA = 0.f, SlA = 0.f;
+        constexpr int nstage = NPASS == 2 ? (MODE == MODE_BWD ? 3 : 2) : 1;
+#pragma unroll 1
+        for (int st = 0; st < nstage; st++) {
+            const bool useB = NPASS == 2 && st == 1;
+            float in[2][5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                in[0][s] = useB ? inA[1][s] : inA[0][s];
+                in[1][s] = useB ? inA[0][s] : inA[1][s];
+            }
+            // =========================== forward ===========================
+            // xb[l][kc][s]: B fragments of layer l's output streams (inputs of layer l+1)
+            u32x4 xb[L - 1][KC][5];
+            u32x2 sv[NW][HT][5];  // saved (h, a_x, a_y, a_z, a_lap) of layers 1..L-1 as bf16
+            // ---- layer 0 on the VALU (K = 2)
+#pragma unroll
+            for (int jt = 0; jt < HT; jt++) {
+                const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + (16 * jt + 4 * g) * 2);
+                const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + (16 * jt + 4 * g) * 2 + 4);
+                const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb0 + 16 * jt + 4 * g);
+                f32x4 a[5];
+#pragma unroll
+                for (int s = 0; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
+                a[0] += b0;
+                f32x4 s0, s1, s2;
+                act012v<ACT>(a[0], s0, s1, s2);
+                const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                f32x4 o[5] = {s0, s1 * a[1], s1 * a[2], s1 * a[3], s1 * a[4] + s2 * q};
+#pragma unroll
+                for (int s = 0; s < 5; s++) {
+                    const u32x2 p = pack4(o[s]);
+                    if (jt & 1) { xb[0][jt >> 1][s][2] = p[0]; xb[0][jt >> 1][s][3] = p[1]; }
+                    else { xb[0][jt >> 1][s][0] = p[0]; xb[0][jt >> 1][s][1] = p[1]; }
+                }
+            }
+            // ---- layers 1..L-1 on the matrix cores
+            float Sv = 0.f, Sl = 0.f;
+#pragma unroll
+            for (int l = 1; l < L; l++) {
+                const __bf16* wf = wpk + (size_t)((l - 1) * 2 + 0) * H * H;
+#pragma unroll
+                for (int jt = 0; jt < HT; jt++) {
+                    f32x4 a[5];
+                    a[0] = *reinterpret_cast<const f32x4*>(sbl + (l - 1) * H + 16 * jt + 4 * g);
+#pragma unroll
+                    for (int s = 1; s < 5; s++) a[s] = splat(0.f);
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wf + ((jt * KC + kc) * 64 + lane) * 8);
+#pragma unroll
+                        for (int s = 0; s < 5; s++) a[s] = mfma(wa, as_frag(xb[l - 1][kc][s]), a[s]);
+                    }
+                    f32x4 s0, s1, s2;
+                    act012v<ACT>(a[0], s0, s1, s2);
+                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                    const f32x4 ol = s1 * a[4] + s2 * q;
+                    sv[l - 1][jt][0] = pack4(s0);
+#pragma unroll
+                    for (int s = 1; s < 5; s++) sv[l - 1][jt][s] = pack4(a[s]);
+                    if (l < L - 1) {
+                        f32x4 o[5] = {s0, s1 * a[1], s1 * a[2], s1 * a[3], ol};
+#pragma unroll
+                        for (int s = 0; s < 5; s++) {
+                            const u32x2 p = pack4(o[s]);
+                            if (jt & 1) { xb[l][jt >> 1][s][2] = p[0]; xb[l][jt >> 1][s][3] = p[1]; }
+                            else { xb[l][jt >> 1][s][0] = p[0]; xb[l][jt >> 1][s][1] = p[1]; }
+                        }
+                    } else {
+                        const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 16 * jt + 4 * g);
+                        const f32x4 pv = wo * s0, pl = wo * ol;
+                        Sv += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                        Sl += (pl[0] + pl[1]) + (pl[2] + pl[3]);
+                    }
+                }
+            }
+            Sv = xg_sum(Sv);
+            Sl = xg_sum(Sl);
+            const bool do_tail = NPASS == 1 || st == 1;
+            if (NPASS == 2 && st == 0) { SvA = Sv; SlA = Sl; }
+            if (do_tail) {
+                if (NPASS == 2) { Sv = SvA + A.P * Sv; Sl = SlA + A.P * Sl; }
+                const float N = A.out_scale * Sv + sbo[0];
+                const float lapN = A.out_scale * Sl;
+                tail<float>(N, lapN, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1, m2, A.invN, invN1,
+                            invN2, valid ? 1.0f : 0.0f, t);
+                if (MODE == MODE_FWD) {
+                    if (valid && g == 0) {
+                        if (A.psi) A.psi[idx] = t.psi;
+                        if (A.lap) A.lap[idx] = t.lap;
+                        if (A.res) A.res[idx] = t.res;
+                    }
+                } else {
+                    if (valid && g == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+                    acc_pde += lead * t.l_pde;
+                    acc_bc1 += lead * t.l_bc1;
+                    acc_bc2 += lead * t.l_bc2;
+                    acc_bout += lead * t.Nb;
+                }
+            }
+            if (!(MODE == MODE_BWD && (NPASS == 1 || st >= 1))) continue;
+            // =========================== reverse ===========================
+            const float pw = useB ? A.P : 1.0f;
+            const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
+            u32x4 yb[KC][5];  // B fragments of the current layer's pre-activation adjoints
+            // ---- last hidden layer: only the value and Laplacian streams feed Lin_out
+#pragma unroll
+            for (int jt = 0; jt < HT; jt++) {
+                const f32x4 h = unpack4(sv[NW - 1][jt][0]);
+                f32x4 a[5];
+#pragma unroll
+                for (int s = 1; s < 5; s++) a[s] = unpack4(sv[NW - 1][jt][s]);
+                f32x4 s1, s2, s3;
+                act123v<ACT>(h, s1, s2, s3);
+                const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 16 * jt + 4 * g);
+                woacc[jt] += cv * h + cl * (s1 * a[4] + s2 * q);
+                const f32x4 o0 = cv * wo, ol = cl * wo;
+                const f32x4 u = 2.0f * s2 * ol;
+                f32x4 ab[5];
+                ab[4] = s1 * ol;
+                ab[1] = u * a[1];
+                ab[2] = u * a[2];
+                ab[3] = u * a[3];
+                ab[0] = s1 * o0 + (s2 * a[4] + s3 * q) * ol;
+                bacc[L - 1][jt] += ab[0];
+#pragma unroll
+                for (int s = 0; s < 5; s++) {
+                    const u32x2 p = pack4(ab[s]);
+                    if (jt & 1) { yb[jt >> 1][s][2] = p[0]; yb[jt >> 1][s][3] = p[1]; }
+                    else { yb[jt >> 1][s][0] = p[0]; yb[jt >> 1][s][1] = p[1]; }
+                }
+            }
+#pragma unroll
+            for (int l = L - 1; l >= 1; l--) {
+                // ---- W_l-bar += Y-bar (x) X over this wave's 80 columns, 32 columns per phase
+#pragma unroll
+                for (int ph = 0; ph < 3; ph++) {
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) {
+                        const int s = 2 * ph + sl;
+#pragma unroll
+                        for (int kc = 0; kc < KC; kc++) {
+                            const u32x4 zy = s < 5 ? yb[kc][s < 5 ? s : 0] : u32x4{0u, 0u, 0u, 0u};
+                            const u32x4 zx = s < 5 ? xb[l - 1][kc][s < 5 ? s : 0] : u32x4{0u, 0u, 0u, 0u};
+                            *reinterpret_cast<u32x4*>(imgY + (16 * sl + c) * PITCH + 32 * kc + 8 * g) = zy;
+                            *reinterpret_cast<u32x4*>(imgX + (16 * sl + c) * PITCH + 32 * kc + 8 * g) = zx;
+                        }
+                    }
+                    wave_fence();
+                    bf16x8 fx[HT];
+#pragma unroll
+                    for (int it = 0; it < HT; it++) {
+                        const __bf16* p0 = imgX + (8 * g + (c >> 2)) * PITCH + 16 * it + 4 * (c & 3);
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)p0);
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(p0 + 4 * PITCH));
+                        fx[it] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < HT; jt++) {
+                        const __bf16* p0 = imgY + (8 * g + (c >> 2)) * PITCH + 16 * jt + 4 * (c & 3);
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)p0);
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(p0 + 4 * PITCH));
+                        const bf16x8 fy = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                        for (int it = 0; it < HT; it++) wacc[l - 1][jt][it] = mfma(fy, fx[it], wacc[l - 1][jt][it]);
+                    }
+                    wave_fence();
+                }
+                // ---- adjoint of layer l's input, one row tile at a time, then layer l-1's
+                //      activation adjoint for exactly those neurons
+                const __bf16* wb = wpk + (size_t)((l - 1) * 2 + 1) * H * H;
+                u32x4 ybn[KC][5];
+#pragma unroll
+                for (int it = 0; it < HT; it++) {
+                    f32x4 ob[5];
+#pragma unroll
+                    for (int s = 0; s < 5; s++) ob[s] = splat(0.f);
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wb + ((it * KC + kc) * 64 + lane) * 8);
+#pragma unroll
+                        for (int s = 0; s < 5; s++) ob[s] = mfma(wa, as_frag(yb[kc][s]), ob[s]);
+                    }
+                    f32x4 h, a[5];
+                    if (l - 1 == 0) {  // recompute layer 0's derivative streams (K = 2); h from its bf16 output
+                        const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + (16 * it + 4 * g) * 2);
+                        const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + (16 * it + 4 * g) * 2 + 4);
+                        const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
+#pragma unroll
+                        for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
+                        const u32x4 hx = xb[0][it >> 1][0];
+                        h = unpack4((it & 1) ? u32x2{hx[2], hx[3]} : u32x2{hx[0], hx[1]});
+                    } else {
+                        h = unpack4(sv[l - 2][it][0]);
+#pragma unroll
+                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[l - 2][it][s]);
+                    }
+                    f32x4 s1, s2, s3;
+                    act123v<ACT>(h, s1, s2, s3);
+                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                    const f32x4 u = 2.0f * s2 * ob[4];
+                    f32x4 ab[5];
+                    ab[4] = s1 * ob[4];
+                    ab[1] = s1 * ob[1] + u * a[1];
+                    ab[2] = s1 * ob[2] + u * a[2];
+                    ab[3] = s1 * ob[3] + u * a[3];
+                    ab[0] = s1 * ob[0] + s2 * (a[1] * ob[1] + a[2] * ob[2] + a[3] * ob[3]) +
+                            (s2 * a[4] + s3 * q) * ob[4];
+                    bacc[l - 1][it] += ab[0];
+                    if (l - 1 == 0) {
+                        f32x4 g0 = splat(0.f), g1 = splat(0.f);
+#pragma unroll
+                        for (int s = 0; s < 5; s++) { g0 += ab[s] * in[0][s]; g1 += ab[s] * in[1][s]; }
+                        w0acc[it][0] += g0;
+                        w0acc[it][1] += g1;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 5; s++) {
+                            const u32x2 p = pack4(ab[s]);
+                            if (it & 1) { ybn[it >> 1][s][2] = p[0]; ybn[it >> 1][s][3] = p[1]; }
+                            else { ybn[it >> 1][s][0] = p[0]; ybn[it >> 1][s][1] = p[1]; }
+                        }
+                    }
+                }
+                if (l - 1 >= 1) {
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+                        for (int s = 0; s < 5; s++) yb[kc][s] = ybn[kc][s];
+                }
+            }
+        }
+    }
+
+    if (MODE == MODE_FWD) return;
+    // =========================== block reduction ===========================
+    __syncthreads();  // images are dead; reuse the LDS front (weights) as the gradient image
+    constexpr int PT = Lay::size;
+    float* gimg = reinterpret_cast<float*>(lds_raw);  // PT floats + 4 scalars
+    float* sc = gimg + PT;
+    const float s0 = row16_sum(xg_sum(acc_pde)), s1r = row16_sum(xg_sum(acc_bc1)),
+                s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
+    // lane-local vector sums -> per (g, neuron) totals over the 16 point columns
+    if (MODE == MODE_BWD) {
+#pragma unroll
+        for (int jt = 0; jt < HT; jt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+#pragma unroll
+                for (int l = 0; l < L; l++) bacc[l][jt][r] = row16_sum(bacc[l][jt][r]);
+                w0acc[jt][0][r] = row16_sum(w0acc[jt][0][r]);
+                w0acc[jt][1][r] = row16_sum(w0acc[jt][1][r]);
+                woacc[jt][r] = row16_sum(woacc[jt][r]);
+            }
+    }
+    for (int w = 0; w < kWavesPerBlock; w++) {
+        if (wave == w) {
+            const bool add = w != 0;
+            if (MODE == MODE_BWD) {
+#pragma unroll
+                for (int l = 1; l < L; l++)
+#pragma unroll
+                    for (int jt = 0; jt < HT; jt++)
+#pragma unroll
+                        for (int it = 0; it < HT; it++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const int nj = q_neuron(16 * jt + 4 * g + r), ni = q_neuron(16 * it + c);
+                                float* p = gimg + Lay::W(l) + nj * H + ni;
+                                *p = add ? *p + wacc[l - 1][jt][it][r] : wacc[l - 1][jt][it][r];
+                            }
+                if (c == 0) {
+#pragma unroll
+                    for (int jt = 0; jt < HT; jt++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int nj = 16 * jt + 4 * g + r;
+#pragma unroll
+                            for (int l = 0; l < L; l++) {
+                                float* p = gimg + Lay::b(l) + nj;
+                                *p = add ? *p + bacc[l][jt][r] : bacc[l][jt][r];
+                            }
+                            float* p0 = gimg + Lay::W(0) + 2 * nj;
+                            p0[0] = add ? p0[0] + w0acc[jt][0][r] : w0acc[jt][0][r];
+                            p0[1] = add ? p0[1] + w0acc[jt][1][r] : w0acc[jt][1][r];
+                            float* po = gimg + Lay::Wout + nj;
+                            *po = add ? *po + woacc[jt][r] : woacc[jt][r];
+                        }
+                }
+            }
+            if (lane == 0) {
+                if (!add) { sc[0] = s0; sc[1] = s1r; sc[2] = s2r; sc[3] = s3r; }
+                else { sc[0] += s0; sc[1] += s1r; sc[2] += s2r; sc[3] += s3r; }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = A.partial + (size_t)blockIdx.x * A.stride;
+    if (MODE == MODE_BWD) {
+        for (int k = threadIdx.x; k < PT; k += kBlock) out[k] = k == Lay::bout ? sc[3] : gimg[k];
+    } else {
+        for (int k = threadIdx.x; k < PT; k += kBlock) out[k] = 0.0f;
+    }
+    if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
+}
+
+template <int H, int L, int ACT, int NPASS, int MODE>
+hipError_t launch_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
+{
+    using C = MCfg<H, L>;
+    const int nfrag = C::NW * 2 * C::HT * C::KC * 64;
+    hipLaunchKernelGGL((k_pack_weights<H, L>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    auto kern = k_trunk_mfma<H, L, ACT, NPASS, MODE>;
+    size_t lds = C::LDS_BYTES;
+    const size_t need = (size_t)(TrunkLayout<H, L>::size + 16) * 4;
+    if (lds < need) lds = need;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, theta, (const __bf16*)wpk, A);
+    return hipGetLastError();
+}
+
+template <int H, int L>
+bool launch_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, const TrunkArgs& A,
+               int grid, hipStream_t st, hipError_t* e)
+{
+#define PINN_MCASE(ACT, NP, MD)                                            \
+    if (act == ACT && npass == NP && mode == MD) {                         \
+        *e = launch_t<H, L, ACT, NP, MD>(theta, wpk, A, grid, st);         \
+        return true;                                                       \
+    }
+    PINN_MCASE(ACT_SIGMOID, 2, MODE_FWD) PINN_MCASE(ACT_SIGMOID, 2, MODE_BWD)
+    PINN_MCASE(ACT_SIGMOID, 1, MODE_FWD) PINN_MCASE(ACT_SIGMOID, 1, MODE_BWD)
+    PINN_MCASE(ACT_TANH, 2, MODE_FWD) PINN_MCASE(ACT_TANH, 2, MODE_BWD)
+    PINN_MCASE(ACT_TANH, 1, MODE_FWD) PINN_MCASE(ACT_TANH, 1, MODE_BWD)
+#undef PINN_MCASE
+    return false;
+}
+
+}  // namespace
+
+bool mfma_trunk_supported(int H, int L) { return H == 64 && L == 2; }
+
+size_t mfma_packed_weight_bytes(int H, int L) { return (size_t)(L - 1) * 2 * H * H * 2; }
+
+int mfma_partial_stride(int H, int L) { return 3 * H + (L - 1) * (H * H + H) + H + 1 + 3; }
+
+bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, const float* theta,
+                       void* packed_weights, const TrunkArgs& A, int grid, hipStream_t st,
+                       hipError_t* err)
+{
+    __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
+    if (H == 64 && L == 2) return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
+    return false;
+}

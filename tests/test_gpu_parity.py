@@ -295,3 +295,58 @@ def test_training_reduces_the_loss_and_full_size_properties():
         tr.step()
     last = tr.losses()
     assert last[0] < 0.2 * first[0], (first, last)
+
+
+# ----------------------------------------------------------------------------- bf16 MFMA path
+# Wide trunk (H = 64) on the matrix cores with bf16 operands.  bf16 cannot meet the 1e-5 bar
+# (SURVEY section 7); the tolerances below are this path's own, stated relative to max-norms:
+#   psi 2e-3, E 1e-5 (E-net stays fp32), lap 1e-2, residual 1e-2, loss 3e-2, gradient 3e-2.
+def _mfma_case(theta, x, y, z, R, mask, act, form, A_or, Hm_or):
+    f = pkg.model.FORMULATION_A if form == "A" else pkg.model.FORMULATION_B
+    arch = capi.Arch(64, 2, 32, 10, act, f["n_pass"], f["out_scale"], capi.PINN_PREC_BF16)
+    h = capi.Handle(arch, 0, 4096)
+    fw = O.forward(A_or, Hm_or, theta, x, y, z, R)
+    ref = O.loss_grad(A_or, Hm_or, theta, x, y, z, R, mask)
+    psi, E, lap, res = run_forward(h, f, theta, x, y, z, R)
+    out = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    P = h.P
+    errs = dict(psi=rel(psi, fw["psi"]), E=rel(E, fw["E"]), lap=rel(lap, fw["lap"]),
+                res=rel(res, fw["res"]), loss=abs(out[P:].sum() / ref["Ltot"] - 1),
+                grad=rel(out[:P], ref["grad"]))
+    off, sz = capi.tensor_layout(arch)
+    names = ["W0", "b0", "W1", "b1", "wout", "bout"]
+    for t, nm in enumerate(names):
+        r = ref["grad"][off[t]:off[t] + sz[t]]
+        errs["g_" + nm] = np.max(np.abs(out[off[t]:off[t] + sz[t]] - r)) / max(np.max(np.abs(r)), 1e-30)
+    print("mfma bf16 errors:", {k: "%.2e" % v for k, v in errs.items()})
+    assert errs["psi"] < 2e-3 and errs["E"] < 1e-5 and errs["lap"] < 1e-2 and errs["res"] < 1e-2
+    assert errs["loss"] < 3e-2 and errs["grad"] < 3e-2
+    for nm in names:
+        assert errs["g_" + nm] < 6e-2, (nm, errs)
+    # E-net / gate gradients come from the fp32 kernels but inherit bf16 noise through dL/dE
+    a = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    assert np.array_equal(a, out)                      # still bitwise reproducible
+
+
+def test_mfma_bf16_wide_trunk_matches_reference(golden_dir):
+    """H = 64 NN_ion (sigmoid, symmetric): golden vector generated by the reference itself"""
+    g = np.load(os.path.join(golden_dir, "g2_formA_rand64.npz"))
+    _mfma_case(g["theta"], g["x"], g["y"], g["z"], g["R"], g["mask"], 0, "A",
+               O.arch(H=64), O.ham_A())
+
+
+def test_mfma_bf16_tanh_single_pass_matches_oracle():
+    """the '2x64 tanh' shape, train.py formulation (one pass, 2h): oracle only"""
+    A = O.arch(H=64, act=1, n_pass=1, out_scale=2.0)
+    rng = np.random.default_rng(11)
+    off, sz = O.tensor_layout(A)
+    theta = np.zeros(O.param_count(A))
+    fan = [2, 2, 64, 64, 64, 64, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    for o, s, fi in zip(off, sz, fan):
+        theta[o:o + s] = rng.uniform(-1, 1, s) / np.sqrt(fi)
+    n = 3000
+    x, y, z = rng.uniform(-18, 18, (3, n))
+    R = rng.uniform(0.2, 3, n)
+    mask = ((np.sqrt((x - R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8)
+            + 2 * (np.sqrt((x + R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8))
+    _mfma_case(theta, x, y, z, R, mask, 1, "B", A, O.ham_B())

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpinn_hip.so")
+LIB_PATH = os.environ.get("PINN_HIP_LIB", os.path.join(HERE, "libpinn_hip.so"))  # override: A/B builds
 
 PINN_ACT_SIGMOID, PINN_ACT_TANH = 0, 1
 PINN_PREC_F32, PINN_PREC_BF16, PINN_PREC_BF16X3 = 0, 1, 2

@@ -130,6 +130,31 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// thT = theta with the forward-contracted matrices stored input-major (see pinn_math.h):
+// W_0 as [2][H], W_l (l >= 1) and WE2 transposed; everything else copied.
+__global__ void k_prep_theta(const float* __restrict__ th, float* __restrict__ thT, int H, int L,
+                             int HE, int PT, int P)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    int src = k;
+    if (k < 2 * H) {                       // thT[c*H + j] = W0[j][c]
+        const int c = k / H, j = k % H;
+        src = 2 * j + c;
+    } else if (k < PT) {
+        const int per = H * H + H;
+        const int r = k - 3 * H;           // offset into the (W_l, b_l) blocks, l >= 1
+        if (r >= 0 && r < (L - 1) * per) {
+            const int l = r / per, o = r % per;
+            if (o < H * H) src = 3 * H + l * per + (o % H) * H + o / H;
+        }
+    } else {
+        const int o = k - PT - 2 * HE;     // WE2 block of the R-net
+        if (o >= 0 && o < HE * HE) src = PT + 2 * HE + (o % HE) * HE + o / HE;
+    }
+    thT[k] = th[src];
+}
+
 // ------------------------------------------------------------- trunk kernel
 template <int H, int L>
 struct TrunkSink {
@@ -245,8 +270,15 @@ struct TrunkSink {
 };
 
 
+// one wave per SIMD: the packed rank-1 formulation keeps ~300 values live; at the 256-register
+// cap of two waves it spills 700 B/lane and runs 1.4x slower (VALU throughput does not depend on
+// occupancy: a wave64 VALU instruction occupies its SIMD for 4 cycles either way)
+#ifndef PINN_TRUNK_MIN_WAVES
+#define PINN_TRUNK_MIN_WAVES 1
+#endif
 template <int H, int L, int ACT, int NPASS, int MODE>
-__global__ __launch_bounds__(kBlock, 2) void k_trunk(const float* __restrict__ th, TrunkArgs A)
+__global__ __launch_bounds__(kBlock, PINN_TRUNK_MIN_WAVES) void k_trunk(const float* __restrict__ th,
+                                                      const float* __restrict__ thT, TrunkArgs A)
 {
     using Lay = TrunkLayout<H, L>;
     constexpr int PT = Lay::size;
@@ -308,7 +340,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_trunk(const float* __restrict__ t
 #pragma unroll
                 for (int s = 0; s < 5; s++) in[c][s] = useB ? inB[c][s] : inA[c][s];
             float Sv = 0.f, Sl = 0.f;
-            tp.forward(launder(th), in, Sv, Sl);
+            tp.forward(launder(th), launder(thT), in, Sv, Sl);
             const bool do_tail = NPASS == 1 || st == 1;
             if (NPASS == 2 && st == 0) { SvA = Sv; SlA = Sl; }
             if (do_tail) {
@@ -333,7 +365,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_trunk(const float* __restrict__ t
             }
             if (MODE == MODE_BWD && (NPASS == 1 || st >= 1)) {
                 const float pw = useB ? A.P : 1.0f;
-                tp.backward(launder(th), in, A.out_scale * pw * t.Nb, A.out_scale * pw * t.lapNb, sink);
+                tp.backward(launder(th), launder(thT), in, A.out_scale * pw * t.Nb, A.out_scale * pw * t.lapNb, sink);
             }
         }
     }
@@ -365,6 +397,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_trunk(const float* __restrict__ t
 // -------------------------------------------------------------- R-only nets
 template <int HE, int HG, int ACT>
 __global__ __launch_bounds__(kBlock) void k_rnet_fwd(const float* __restrict__ th_r,
+                                                     const float* __restrict__ thT_r,
                                                      const float* __restrict__ R, int64_t n,
                                                      float* __restrict__ E, float* __restrict__ g,
                                                      float* __restrict__ E_user)
@@ -373,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void k_rnet_fwd(const float* __restrict__ t
          i += (int64_t)gridDim.x * kBlock) {
         Rnet<HE, HG, ACT, float> rn;
         float e, gg;
-        rn.forward(launder(th_r), R[i], e, gg);
+        rn.forward(launder(th_r), launder(thT_r), R[i], e, gg);
         E[i] = e;
         g[i] = gg;
         if (E_user) E_user[i] = e;
@@ -487,6 +520,7 @@ struct RnetSink {
 
 template <int HE, int HG, int ACT>
 __global__ __launch_bounds__(kBlock) void k_rnet_bwd(const float* __restrict__ th_r,
+                                                     const float* __restrict__ thT_r,
                                                      const float* __restrict__ R,
                                                      const float* __restrict__ Eb,
                                                      const float* __restrict__ gb, int64_t n,
@@ -515,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_rnet_bwd(const float* __restrict__ t
         const float eb = valid ? Eb[id] : 0.0f, gbv = valid ? gb[id] : 0.0f;
         Rnet<HE, HG, ACT, float> rn;
         float e, gg;
-        rn.forward(launder(th_r), Rv, e, gg);
+        rn.forward(launder(th_r), launder(thT_r), Rv, e, gg);
         rn.backward(launder(th_r), Rv, eb, gbv, sink);
     }
     const float sE3 = wave_sum(sink.bE3), sG2 = wave_sum(sink.bG2);
@@ -702,6 +736,7 @@ struct pinn_handle {
     float *E, *g, *Eb, *gb; // per-point scratch
     float *partT, *partR;   // per-block partials
     void* wpk;              // packed bf16 weights (MFMA path)
+    float* thT;             // theta with forward matrices input-major (k_prep_theta)
     uint8_t* tensor_of;     // [P] tensor index of each parameter
     uint64_t trunk_tensors; // bits of the trunk tensors
     int prof_slots;          // 0 = off
@@ -783,18 +818,19 @@ namespace {
 struct TrunkKey { int H, L, act, npass, mode; };
 
 template <int H, int L, int ACT, int NPASS, int MODE>
-static hipError_t launch_trunk_t(const float* theta, const TrunkArgs& A, int grid, hipStream_t st)
+static hipError_t launch_trunk_t(const float* theta, const float* thT, const TrunkArgs& A, int grid,
+                                 hipStream_t st)
 {
-    hipLaunchKernelGGL((k_trunk<H, L, ACT, NPASS, MODE>), dim3(grid), dim3(kBlock), 0, st, theta, A);
+    hipLaunchKernelGGL((k_trunk<H, L, ACT, NPASS, MODE>), dim3(grid), dim3(kBlock), 0, st, theta, thT, A);
     return hipGetLastError();
 }
 
 template <int H, int L>
-static int launch_trunk_HL(const TrunkKey& k, const float* theta, const TrunkArgs& A, int grid, hipStream_t st, hipError_t* e)
+static int launch_trunk_HL(const TrunkKey& k, const float* theta, const float* thT, const TrunkArgs& A, int grid, hipStream_t st, hipError_t* e)
 {
 #define PINN_CASE(ACT, NP, MD)                                                     \
     if (k.act == ACT && k.npass == NP && k.mode == MD) {                           \
-        *e = launch_trunk_t<H, L, ACT, NP, MD>(theta, A, grid, st);                      \
+        *e = launch_trunk_t<H, L, ACT, NP, MD>(theta, thT, A, grid, st);                      \
         return 1;                                                                  \
     }
     PINN_CASE(ACT_SIGMOID, 2, MODE_FWD) PINN_CASE(ACT_SIGMOID, 2, MODE_BWD) PINN_CASE(ACT_SIGMOID, 2, MODE_HEAD)
@@ -805,10 +841,10 @@ static int launch_trunk_HL(const TrunkKey& k, const float* theta, const TrunkArg
     return 0;
 }
 
-static int launch_trunk(const TrunkKey& k, const float* theta, const TrunkArgs& A, int grid, hipStream_t st, hipError_t* e)
+static int launch_trunk(const TrunkKey& k, const float* theta, const float* thT, const TrunkArgs& A, int grid, hipStream_t st, hipError_t* e)
 {
-    if (k.H == 16 && k.L == 2) return launch_trunk_HL<16, 2>(k, theta, A, grid, st, e);
-    if (k.H == 16 && k.L == 3) return launch_trunk_HL<16, 3>(k, theta, A, grid, st, e);
+    if (k.H == 16 && k.L == 2) return launch_trunk_HL<16, 2>(k, theta, thT, A, grid, st, e);
+    if (k.H == 16 && k.L == 3) return launch_trunk_HL<16, 3>(k, theta, thT, A, grid, st, e);
     return 0;
 }
 
@@ -816,49 +852,58 @@ static bool trunk_supported(int H, int L) { return H == 16 && (L == 2 || L == 3)
 static bool rnet_supported(int HE, int HG) { return (HE == 32 && HG == 10) || (HE == 16 && HG == 8); }
 
 template <int HE, int HG>
-static int launch_rnet_fwd_s(int act, const float* th, const float* R, int64_t n, float* E, float* g,
-                             float* Eu, int grid, hipStream_t st, hipError_t* e)
+static int launch_rnet_fwd_s(int act, const float* th, const float* thT, const float* R, int64_t n,
+                             float* E, float* g, float* Eu, int grid, hipStream_t st, hipError_t* e)
 {
     if (act == ACT_SIGMOID)
-        hipLaunchKernelGGL((k_rnet_fwd<HE, HG, ACT_SIGMOID>), dim3(grid), dim3(kBlock), 0, st, th, R, n, E, g, Eu);
+        hipLaunchKernelGGL((k_rnet_fwd<HE, HG, ACT_SIGMOID>), dim3(grid), dim3(kBlock), 0, st, th, thT, R, n, E, g, Eu);
     else
-        hipLaunchKernelGGL((k_rnet_fwd<HE, HG, ACT_TANH>), dim3(grid), dim3(kBlock), 0, st, th, R, n, E, g, Eu);
+        hipLaunchKernelGGL((k_rnet_fwd<HE, HG, ACT_TANH>), dim3(grid), dim3(kBlock), 0, st, th, thT, R, n, E, g, Eu);
     *e = hipGetLastError();
     return 1;
 }
 
-static int launch_rnet_fwd(int HE, int HG, int act, const float* th, const float* R, int64_t n,
-                           float* E, float* g, float* Eu, int grid, hipStream_t st, hipError_t* e)
+static int launch_rnet_fwd(int HE, int HG, int act, const float* th, const float* thT, const float* R,
+                           int64_t n, float* E, float* g, float* Eu, int grid, hipStream_t st,
+                           hipError_t* e)
 {
-    if (HE == 32 && HG == 10) return launch_rnet_fwd_s<32, 10>(act, th, R, n, E, g, Eu, grid, st, e);
-    if (HE == 16 && HG == 8) return launch_rnet_fwd_s<16, 8>(act, th, R, n, E, g, Eu, grid, st, e);
+    if (HE == 32 && HG == 10) return launch_rnet_fwd_s<32, 10>(act, th, thT, R, n, E, g, Eu, grid, st, e);
+    if (HE == 16 && HG == 8) return launch_rnet_fwd_s<16, 8>(act, th, thT, R, n, E, g, Eu, grid, st, e);
     return 0;
 }
 
 template <int HE, int HG>
-static int launch_rnet_bwd_s(int act, const float* th, const float* R, const float* Eb,
+static int launch_rnet_bwd_s(int act, const float* th, const float* thT, const float* R, const float* Eb,
                              const float* gb, int64_t n, float* part, int stride, int grid,
                              hipStream_t st, hipError_t* e)
 {
     const size_t shm = 0;
     if (act == ACT_SIGMOID)
-        hipLaunchKernelGGL((k_rnet_bwd<HE, HG, ACT_SIGMOID>), dim3(grid), dim3(kBlock), shm, st, th, R, Eb, gb, n, part, stride);
+        hipLaunchKernelGGL((k_rnet_bwd<HE, HG, ACT_SIGMOID>), dim3(grid), dim3(kBlock), shm, st, th, thT, R, Eb, gb, n, part, stride);
     else
-        hipLaunchKernelGGL((k_rnet_bwd<HE, HG, ACT_TANH>), dim3(grid), dim3(kBlock), shm, st, th, R, Eb, gb, n, part, stride);
+        hipLaunchKernelGGL((k_rnet_bwd<HE, HG, ACT_TANH>), dim3(grid), dim3(kBlock), shm, st, th, thT, R, Eb, gb, n, part, stride);
     *e = hipGetLastError();
     return 1;
 }
 
-static int launch_rnet_bwd(int HE, int HG, int act, const float* th, const float* R, const float* Eb,
+static int launch_rnet_bwd(int HE, int HG, int act, const float* th, const float* thT, const float* R, const float* Eb,
                            const float* gb, int64_t n, float* part, int stride, int grid,
                            hipStream_t st, hipError_t* e)
 {
-    if (HE == 32 && HG == 10) return launch_rnet_bwd_s<32, 10>(act, th, R, Eb, gb, n, part, stride, grid, st, e);
-    if (HE == 16 && HG == 8) return launch_rnet_bwd_s<16, 8>(act, th, R, Eb, gb, n, part, stride, grid, st, e);
+    if (HE == 32 && HG == 10) return launch_rnet_bwd_s<32, 10>(act, th, thT, R, Eb, gb, n, part, stride, grid, st, e);
+    if (HE == 16 && HG == 8) return launch_rnet_bwd_s<16, 8>(act, th, thT, R, Eb, gb, n, part, stride, grid, st, e);
     return 0;
 }
 
 }  // namespace
+
+static hipError_t prep_theta(pinn_handle* h, const float* theta, hipStream_t st)
+{
+    const pinn_arch& a = h->arch;
+    hipLaunchKernelGGL(k_prep_theta, dim3((h->P + 255) / 256), dim3(256), 0, st, theta, h->thT, a.H, a.L,
+                       a.HE, h->PT, h->P);
+    return hipGetLastError();
+}
 
 static int run_trunk(pinn_handle* h, int mode, const float* theta, const TrunkArgs& A, int grid,
                      hipStream_t st, hipError_t* e)
@@ -866,7 +911,7 @@ static int run_trunk(pinn_handle* h, int mode, const float* theta, const TrunkAr
     const pinn_arch& a = h->arch;
     if (a.precision == PINN_PREC_F32) {
         const TrunkKey k{a.H, a.L, a.act, a.n_pass, mode};
-        return launch_trunk(k, theta, A, grid, st, e);
+        return launch_trunk(k, theta, h->thT, A, grid, st, e);
     }
     return launch_trunk_mfma(a.H, a.L, a.act, a.n_pass, mode, theta, h->wpk, A, grid, st, e) ? 1 : 0;
 }
@@ -899,9 +944,8 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int64_t tiles = (max_points + kBlock - 1) / kBlock;
-    // resident blocks per CU: 2 for the fp32 VALU trunk (2 waves/SIMD), 1 for the MFMA trunk
-    const int per_cu = arch->precision == PINN_PREC_F32 ? 2 : 1;
-    h->nbT = (int)(tiles < (int64_t)cus * per_cu ? tiles : (int64_t)cus * per_cu);
+    // one resident 4-wave block per CU for both trunk kernels (1 wave per SIMD)
+    h->nbT = (int)(tiles < (int64_t)cus ? tiles : (int64_t)cus);
     h->nbR = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
     h->strideT = h->PT + 3;
     h->strideR = h->PR;
@@ -912,6 +956,7 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     HIPCHK(h, hipMalloc(&h->partT, sizeof(float) * (size_t)h->nbT * h->strideT));
     HIPCHK(h, hipMalloc(&h->partR, sizeof(float) * (size_t)h->nbR * h->strideR));
     HIPCHK(h, hipMalloc(&h->tensor_of, h->P));
+    HIPCHK(h, hipMalloc(&h->thT, sizeof(float) * h->P));
     if (arch->precision != PINN_PREC_F32)
         HIPCHK(h, hipMalloc(&h->wpk, mfma_packed_weight_bytes(arch->H, arch->L)));
     {
@@ -987,6 +1032,7 @@ extern "C" int pinn_destroy(pinn_handle* h)
     (void)hipFree(h->E); (void)hipFree(h->g); (void)hipFree(h->Eb); (void)hipFree(h->gb);
     (void)hipFree(h->partT); (void)hipFree(h->partR); (void)hipFree(h->tensor_of);
     if (h->wpk) (void)hipFree(h->wpk);
+    (void)hipFree(h->thT);
     delete h;
     return PINN_OK;
 }
@@ -1016,7 +1062,9 @@ extern "C" int pinn_forward(pinn_handle* h, const float* theta, const float* x, 
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     const pinn_arch& a = h->arch;
-    if (!launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, R, n, h->E, h->g, E, grid_for(n, h->nbR * 4), st, &e))
+    e = prep_theta(h, theta, st);
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_prep_theta", e);
+    if (!launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, n, h->E, h->g, E, grid_for(n, h->nbR * 4), st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_fwd", e);
     if (!psi && !lap && !res) return PINN_OK;
@@ -1044,7 +1092,9 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     hipError_t e = hipSuccess;
     const pinn_arch& a = h->arch;
     const int gT = grid_for(n, h->nbT), gR = grid_for(n, h->nbR);
-    if (!launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, R, n, h->E, h->g, nullptr, grid_for(n, h->nbR * 4), st, &e))
+    e = prep_theta(h, theta, st);
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_prep_theta", e);
+    if (!launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, n, h->E, h->g, nullptr, grid_for(n, h->nbR * 4), st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_fwd", e);
     TrunkArgs A{};
@@ -1063,7 +1113,7 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
         HIPCHK(h, hipEventRecord(h->ev[2 * slot + 1], st));
         h->prof_calls++;
     }
-    if (!launch_rnet_bwd(a.HE, a.HG, a.act, theta + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st, &e))
+    if (!launch_rnet_bwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_bwd", e);
     const int tot = h->P + 3;

@@ -25,8 +25,13 @@
 // s_load next to the FMAs that consume it.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PINN_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+// sched_barrier orders machine instructions only; instruction selection is still free to sink
+// pure arithmetic below later loads.  An empty volatile asm on a region's result pins the
+// FMAs that produce it inside the region (no instruction is emitted).
+#define PINN_PIN(x) asm volatile("" : "+v"(x))
 #else
 #define PINN_ROW_FENCE() ((void)0)
+#define PINN_PIN(x) ((void)0)
 #endif
 
 namespace pinn {
@@ -47,6 +52,20 @@ PINN_HD float p_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 PINN_HD double p_exp(double x) { return std::exp(x); }
 PINN_HD double p_rcp(double x) { return 1.0 / x; }
 PINN_HD double p_rsqrt(double x) { return 1.0 / std::sqrt(x); }
+
+// Two neurons side by side.  The fp32 vector peak of gfx950 (157 TFLOP/s) is the PACKED rate:
+// a wave64 VALU instruction takes 4 cycles whether it is v_fmac_f32 or v_pk_fma_f32, so every
+// mat-vec below is written as rank-1 updates on neuron PAIRS: acc2[p] += w2[p] * splat(x), which
+// hipcc turns into v_pk_fma_f32 v[..], s[pair], v[..] op_sel_hi:[1,0,0] (weights stay in SGPRs).
+template <class T> struct V2;
+template <> struct V2<float> { typedef float type __attribute__((vector_size(8))); };
+template <> struct V2<double> { typedef double type __attribute__((vector_size(16))); };
+template <class T> PINN_HD typename V2<T>::type splat2(T x) { typename V2<T>::type v = {x, x}; return v; }
+template <class T> PINN_HD typename V2<T>::type make2(T x, T y) { typename V2<T>::type v = {x, y}; return v; }
+
+// thT = theta with every matrix that the FORWARD pass contracts over its input index stored
+// input-major: W_l (l >= 1) and WE2 transposed in place, W_0 as [2][H].  Everything else is
+// copied.  Built once per call (k_prep_theta on the device, prep_theta_host in the CPU check).
 
 // value, first and second derivative of the hidden activation
 // (sigmoid: poc/main.py:231, train.py:45; tanh: build extension)
@@ -142,40 +161,97 @@ struct TrunkPass {
     // Forward.  Adds sum_j wout[j]*B_v[j] to Sv and sum_j wout[j]*B_lap[j] to Sl
     // (Lin_out, poc/main.py:261; train.py:47).
     template <class W>
-    PINN_HD void forward(const W* __restrict__ th, const T (&in)[2][5], T& Sv, T& Sl)
+    PINN_HD void forward(const W* __restrict__ th, const W* __restrict__ thT, const T (&in)[2][5],
+                         T& Sv, T& Sl)
     {
+        using V = typename V2<T>::type;
+        constexpr int HP = H / 2;
+        static_assert(H % 2 == 0, "trunk width must be even");
+        {   // ---- layer 0 (K = 2): two rank-1 updates on neuron pairs
+            V A[5][HP];
+            {
+                V w0[HP], w1[HP], b0[HP];
 #pragma unroll
-        for (int j = 0; j < H; j++) {
-            T w0 = T(th[Lay::W(0) + 2 * j]), w1 = T(th[Lay::W(0) + 2 * j + 1]);
-            T a0 = w0 * in[0][0] + w1 * in[1][0] + T(th[Lay::b(0) + j]);
-            T ax = w0 * in[0][1] + w1 * in[1][1];
-            T ay = w0 * in[0][2] + w1 * in[1][2];
-            T az = w0 * in[0][3] + w1 * in[1][3];
-            T al = w0 * in[0][4] + w1 * in[1][4];
-            T s, s1, s2;
-            act012<ACT>(a0, s, s1, s2);
-            o[0][0][j] = s;
-            o[0][1][j] = s1 * ax;
-            o[0][2][j] = s1 * ay;
-            o[0][3][j] = s1 * az;
-            o[0][4][j] = s1 * al + s2 * (ax * ax + ay * ay + az * az);
+                for (int p = 0; p < HP; p++) {
+                    w0[p] = make2<T>(T(thT[Lay::W(0) + 2 * p]), T(thT[Lay::W(0) + 2 * p + 1]));
+                    w1[p] = make2<T>(T(thT[Lay::W(0) + H + 2 * p]), T(thT[Lay::W(0) + H + 2 * p + 1]));
+                    b0[p] = make2<T>(T(th[Lay::b(0) + 2 * p]), T(th[Lay::b(0) + 2 * p + 1]));
+                }
+                PINN_ROW_FENCE();
+#pragma unroll
+                for (int s = 0; s < 5; s++) {
+                    const V x0 = splat2<T>(in[0][s]), x1 = splat2<T>(in[1][s]);
+#pragma unroll
+                    for (int p = 0; p < HP; p++) {
+                        A[s][p] = w0[p] * x0 + w1[p] * x1;
+                        if (s == 0) A[s][p] += b0[p];
+                    }
+                }
+                PINN_ROW_FENCE();
+            }
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                const T a0 = A[0][j >> 1][j & 1], ax = A[1][j >> 1][j & 1], ay = A[2][j >> 1][j & 1],
+                        az = A[3][j >> 1][j & 1], al = A[4][j >> 1][j & 1];
+                T s, s1, s2;
+                act012<ACT>(a0, s, s1, s2);
+                o[0][0][j] = s;
+                o[0][1][j] = s1 * ax;
+                o[0][2][j] = s1 * ay;
+                o[0][3][j] = s1 * az;
+                o[0][4][j] = s1 * al + s2 * (ax * ax + ay * ay + az * az);
+            }
             PINN_ROW_FENCE();
         }
 #pragma unroll
         for (int l = 1; l < L; l++) {
+            // A[s][p] accumulates the pre-activations of neuron pair p; input i contributes the
+            // rank-1 update (row i of W_l^T) x o_{l-1,s}[i].  Rows are double-buffered so the
+            // scalar-load latency hides behind the 5*H/2 packed FMAs of a row.
+            V A[5][HP];
+#pragma unroll
+            for (int p = 0; p < HP; p++) {
+                A[0][p] = make2<T>(T(th[Lay::b(l) + 2 * p]), T(th[Lay::b(l) + 2 * p + 1]));
+#pragma unroll
+                for (int s = 1; s < 5; s++) A[s][p] = splat2<T>(T(0));
+            }
+            V wc[HP], wn[HP];
+#pragma unroll
+            for (int p = 0; p < HP; p++)
+                wc[p] = make2<T>(T(thT[Lay::W(l) + 2 * p]), T(thT[Lay::W(l) + 2 * p + 1]));
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int i = 0; i < H; i++) {
+                if (i + 1 < H) {
+#pragma unroll
+                    for (int p = 0; p < HP; p++)
+                        wn[p] = make2<T>(T(thT[Lay::W(l) + (i + 1) * H + 2 * p]),
+                                         T(thT[Lay::W(l) + (i + 1) * H + 2 * p + 1]));
+                }
+                PINN_ROW_FENCE();
+#pragma unroll
+                for (int s = 0; s < 5; s++) {
+                    const V xs = splat2<T>(o[l - 1][s][i]);
+#pragma unroll
+                    for (int p = 0; p < HP; p++) {
+                        A[s][p] += wc[p] * xs;
+                        PINN_PIN(A[s][p]);
+                    }
+                }
+                PINN_ROW_FENCE();
+#pragma unroll
+                for (int p = 0; p < HP; p++) wc[p] = wn[p];
+            }
+            T wo_[H];
+            if (l == L - 1) {
+#pragma unroll
+                for (int j = 0; j < H; j++) wo_[j] = T(th[Lay::Wout + j]);
+                PINN_ROW_FENCE();
+            }
 #pragma unroll
             for (int j = 0; j < H; j++) {
-                const W* __restrict__ wr = th + Lay::W(l) + j * H;
-                T c0 = T(th[Lay::b(l) + j]), cx = T(0), cy = T(0), cz = T(0), cl = T(0);
-#pragma unroll
-                for (int i = 0; i < H; i++) {
-                    T w = T(wr[i]);
-                    c0 += w * o[l - 1][0][i];
-                    cx += w * o[l - 1][1][i];
-                    cy += w * o[l - 1][2][i];
-                    cz += w * o[l - 1][3][i];
-                    cl += w * o[l - 1][4][i];
-                }
+                const T c0 = A[0][j >> 1][j & 1], cx = A[1][j >> 1][j & 1], cy = A[2][j >> 1][j & 1],
+                        cz = A[3][j >> 1][j & 1], cl = A[4][j >> 1][j & 1];
                 T s, s1, s2;
                 act012<ACT>(c0, s, s1, s2);
                 a[l - 1][0][j] = s;
@@ -191,12 +267,11 @@ struct TrunkPass {
                     o[l][3][j] = s1 * cz;
                     o[l][4][j] = ol;
                 } else {
-                    T wo = T(th[Lay::Wout + j]);
-                    Sv += wo * s;
-                    Sl += wo * ol;
+                    Sv += wo_[j] * s;
+                    Sl += wo_[j] * ol;
                 }
-                PINN_ROW_FENCE();
             }
+            PINN_ROW_FENCE();
         }
     }
 
@@ -205,13 +280,19 @@ struct TrunkPass {
     // The sink receives, per layer, U = pre-activation adjoint streams and
     // V = that layer's input streams; it owns the reduction over points.
     template <class W, class Sink>
-    PINN_HD void backward(const W* __restrict__ th, const T (&in)[2][5], T cv, T cl, Sink& sink)
+    PINN_HD void backward(const W* __restrict__ th, const W* __restrict__ thT, const T (&in)[2][5],
+                          T cv, T cl, Sink& sink)
     {
+        using V = typename V2<T>::type;
+        constexpr int HP = H / 2;
         T ob[5][H];  // adjoint of the current layer's post-activation streams
         T ab[5][H];  // adjoint of its pre-activation streams
         // ---- last hidden layer: only the value and Laplacian streams feed Lin_out
         {
-            T t[H];
+            T t[H], wo_[H];
+#pragma unroll
+            for (int j = 0; j < H; j++) wo_[j] = T(th[Lay::Wout + j]);
+            PINN_ROW_FENCE();
 #pragma unroll
             for (int j = 0; j < H; j++) {
                 T s = a[L - 2][0][j], ax = a[L - 2][1][j], ay = a[L - 2][2][j],
@@ -220,7 +301,7 @@ struct TrunkPass {
                 act123<ACT>(s, s1, s2, s3);
                 T q = ax * ax + ay * ay + az * az;
                 t[j] = cv * s + cl * (s1 * al + s2 * q);  // d/d wout[j]
-                T wo = T(th[Lay::Wout + j]);
+                T wo = wo_[j];
                 T o0 = cv * wo, ol = cl * wo;
                 T u = T(2) * s2 * ol;
                 ab[4][j] = s1 * ol;
@@ -228,8 +309,8 @@ struct TrunkPass {
                 ab[2][j] = u * ay;
                 ab[3][j] = u * az;
                 ab[0][j] = s1 * o0 + (s2 * al + s3 * q) * ol;
-                PINN_ROW_FENCE();
             }
+            PINN_ROW_FENCE();
             sink.out_weight(t);
         }
 #pragma unroll
@@ -256,28 +337,53 @@ struct TrunkPass {
                 // W_l-bar += ab_s (x) o_{l-1,s}; the s == 0 call also carries b_l-bar += ab_0
                 sink.weight(l, s, ab[s], o[l - 1][s]);
             }
-            // adjoint of the layer input: ob_s = W_l^T ab_s, walked row by row so that
-            // each weight row is one contiguous scalar load feeding 5*H FMAs
+            // adjoint of the layer input: ob_s = W_l^T ab_s as rank-1 updates on input-neuron
+            // pairs: row j of W_l (contiguous, double-buffered scalar loads) x ab_s[j]
+            V ob2[5][HP];
 #pragma unroll
             for (int s = 0; s < 5; s++)
 #pragma unroll
-                for (int i = 0; i < H; i++) ob[s][i] = T(0);
+                for (int p = 0; p < HP; p++) ob2[s][p] = splat2<T>(T(0));
+            V wc[HP], wn[HP];
+#pragma unroll
+            for (int p = 0; p < HP; p++)
+                wc[p] = make2<T>(T(th[Lay::W(l) + 2 * p]), T(th[Lay::W(l) + 2 * p + 1]));
+            PINN_ROW_FENCE();
 #pragma unroll
             for (int j = 0; j < H; j++) {
-                const W* __restrict__ wr = th + Lay::W(l) + j * H;
+                if (j + 1 < H) {
 #pragma unroll
-                for (int i = 0; i < H; i++) {
-                    T w = T(wr[i]);
-#pragma unroll
-                    for (int s = 0; s < 5; s++) ob[s][i] += w * ab[s][j];
+                    for (int p = 0; p < HP; p++)
+                        wn[p] = make2<T>(T(th[Lay::W(l) + (j + 1) * H + 2 * p]),
+                                         T(th[Lay::W(l) + (j + 1) * H + 2 * p + 1]));
                 }
                 PINN_ROW_FENCE();
+#pragma unroll
+                for (int s = 0; s < 5; s++) {
+                    const V xs = splat2<T>(ab[s][j]);
+#pragma unroll
+                    for (int p = 0; p < HP; p++) {
+                        ob2[s][p] += wc[p] * xs;
+                        PINN_PIN(ob2[s][p]);
+                    }
+                }
+                PINN_ROW_FENCE();
+#pragma unroll
+                for (int p = 0; p < HP; p++) wc[p] = wn[p];
             }
+#pragma unroll
+            for (int s = 0; s < 5; s++)
+#pragma unroll
+                for (int i = 0; i < H; i++) ob[s][i] = ob2[s][i >> 1][i & 1];
         }
         // ---- layer 0: recompute its pre-activation derivative streams (K = 2)
+        T w0_[2 * H];
+#pragma unroll
+        for (int k = 0; k < 2 * H; k++) w0_[k] = T(thT[Lay::W(0) + k]);  // [2][H]
+        PINN_ROW_FENCE();
 #pragma unroll
         for (int j = 0; j < H; j++) {
-            T w0 = T(th[Lay::W(0) + 2 * j]), w1 = T(th[Lay::W(0) + 2 * j + 1]);
+            T w0 = w0_[j], w1 = w0_[H + j];
             T ax = w0 * in[0][1] + w1 * in[1][1];
             T ay = w0 * in[0][2] + w1 * in[1][2];
             T az = w0 * in[0][3] + w1 * in[1][3];
@@ -337,64 +443,162 @@ template <int HE, int HG, int ACT, class T>
 struct Rnet {
     T h1[HE], h2[HE], hg[HG];
 
+    static constexpr int CH = HE % 16 == 0 ? 16 : HE;  // scalar-load chunk (one s_load_dwordx16)
+    static constexpr int NCH = HE / CH;                // chunks per weight row
+
     template <class W>
-    PINN_HD void forward(const W* __restrict__ th, T R, T& E, T& g)
+    PINN_HD void forward(const W* __restrict__ th, const W* __restrict__ thT, T R, T& E, T& g)
     {
-        const RnetLayout Lo{HE, HG};
+        constexpr RnetLayout Lo{HE, HG};
         T s1, s2;
+        // first E layer and the gate: small vectors, fetched in batches of 16 scalars
 #pragma unroll
-        for (int j = 0; j < HE; j++)
-            act012<ACT>(T(th[Lo.WE1() + j]) * R + T(th[Lo.bE1() + j]), h1[j], s1, s2);
+        for (int c0 = 0; c0 < HE; c0 += CH) {
+            T w1[CH], b1[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) { w1[j] = T(th[Lo.WE1() + c0 + j]); b1[j] = T(th[Lo.bE1() + c0 + j]); }
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < CH; j++) act012<ACT>(w1[j] * R + b1[j], h1[c0 + j], s1, s2);
+            PINN_ROW_FENCE();
+        }
+        {
+            T wg1[HG], bg1[HG], wg2[HG];
+#pragma unroll
+            for (int j = 0; j < HG; j++) {
+                wg1[j] = T(th[Lo.WG1() + j]); bg1[j] = T(th[Lo.bG1() + j]); wg2[j] = T(th[Lo.WG2() + j]);
+            }
+            T gg = T(th[Lo.bG2()]);
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < HG; j++) {
+                act012<ACT>(wg1[j] * R + bg1[j], hg[j], s1, s2);
+                gg += wg2[j] * hg[j];
+            }
+            g = gg;
+            PINN_ROW_FENCE();
+        }
+        // second E layer: pre-activations of output-neuron pairs accumulate rank-1 updates
+        // (row i of WE2^T) x h1[i]; rows are walked in 16-float chunks, double-buffered
+        using V = typename V2<T>::type;
+        constexpr int CP = CH / 2;
+        static_assert(CH % 2 == 0, "E-net width must be even");
+        V A2[HE / 2];
+#pragma unroll
+        for (int p = 0; p < HE / 2; p++)
+            A2[p] = make2<T>(T(th[Lo.bE2() + 2 * p]), T(th[Lo.bE2() + 2 * p + 1]));
+        V wc[CP], wn[CP];
+#pragma unroll
+        for (int p = 0; p < CP; p++)
+            wc[p] = make2<T>(T(thT[Lo.WE2() + 2 * p]), T(thT[Lo.WE2() + 2 * p + 1]));
+        PINN_ROW_FENCE();
+#pragma unroll
+        for (int q = 0; q < HE * NCH; q++) {
+            const int i = q / NCH, part = q % NCH;
+            if (q + 1 < HE * NCH) {
+#pragma unroll
+                for (int p = 0; p < CP; p++)
+                    wn[p] = make2<T>(T(thT[Lo.WE2() + (q + 1) * CH + 2 * p]),
+                                     T(thT[Lo.WE2() + (q + 1) * CH + 2 * p + 1]));
+            }
+            PINN_ROW_FENCE();
+            const V xs = splat2<T>(h1[i]);
+#pragma unroll
+            for (int p = 0; p < CP; p++) {
+                A2[part * CP + p] += wc[p] * xs;
+                PINN_PIN(A2[part * CP + p]);
+            }
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int p = 0; p < CP; p++) wc[p] = wn[p];
+        }
         T e = T(th[Lo.bE3()]);
 #pragma unroll
-        for (int j = 0; j < HE; j++) {
-            T acc = T(th[Lo.bE2() + j]);
+        for (int c0 = 0; c0 < HE; c0 += CH) {
+            T w3[CH];
 #pragma unroll
-            for (int i = 0; i < HE; i++) acc += T(th[Lo.WE2() + j * HE + i]) * h1[i];
-            act012<ACT>(acc, h2[j], s1, s2);
-            e += T(th[Lo.WE3() + j]) * h2[j];
+            for (int j = 0; j < CH; j++) w3[j] = T(th[Lo.WE3() + c0 + j]);
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                act012<ACT>(A2[(c0 + j) >> 1][(c0 + j) & 1], h2[c0 + j], s1, s2);
+                e += w3[j] * h2[c0 + j];
+            }
             PINN_ROW_FENCE();
         }
         E = e;
-        T gg = T(th[Lo.bG2()]);
-#pragma unroll
-        for (int j = 0; j < HG; j++) {
-            act012<ACT>(T(th[Lo.WG1() + j]) * R + T(th[Lo.bG1() + j]), hg[j], s1, s2);
-            gg += T(th[Lo.WG2() + j]) * hg[j];
-        }
-        g = gg;
     }
 
     // after forward(): push Eb, gb back to the parameters through the sink
     template <class W, class Sink>
     PINN_HD void backward(const W* __restrict__ th, T R, T Eb, T gb, Sink& sink)
     {
-        const RnetLayout Lo{HE, HG};
+        constexpr RnetLayout Lo{HE, HG};
         T a2[HE], t3[HE];
 #pragma unroll
-        for (int j = 0; j < HE; j++) {
-            t3[j] = Eb * h2[j];
-            a2[j] = Eb * T(th[Lo.WE3() + j]) * act1_from_value<ACT>(h2[j]);
+        for (int c0 = 0; c0 < HE; c0 += CH) {
+            T w3[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) w3[j] = T(th[Lo.WE3() + c0 + j]);
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                t3[c0 + j] = Eb * h2[c0 + j];
+                a2[c0 + j] = Eb * w3[j] * act1_from_value<ACT>(h2[c0 + j]);
+            }
+            PINN_ROW_FENCE();
         }
         sink.e3(t3, Eb);          // WE3-bar, bE3-bar
         sink.e2(a2, h1);          // WE2-bar = a2 (x) h1, bE2-bar = a2
         T a1[HE];
+        {   // a1 = WE2^T a2: rank-1 updates on input-neuron pairs, natural rows of WE2 in
+            // double-buffered 16-float chunks
+            using V = typename V2<T>::type;
+            constexpr int CP = CH / 2;
+            V A1[HE / 2];
 #pragma unroll
-        for (int i = 0; i < HE; i++) a1[i] = T(0);
+            for (int p = 0; p < HE / 2; p++) A1[p] = splat2<T>(T(0));
+            V wc[CP], wn[CP];
 #pragma unroll
-        for (int j = 0; j < HE; j++) {  // row-major walk of WE2 (contiguous scalar loads)
-#pragma unroll
-            for (int i = 0; i < HE; i++) a1[i] += T(th[Lo.WE2() + j * HE + i]) * a2[j];
+            for (int p = 0; p < CP; p++)
+                wc[p] = make2<T>(T(th[Lo.WE2() + 2 * p]), T(th[Lo.WE2() + 2 * p + 1]));
             PINN_ROW_FENCE();
-        }
 #pragma unroll
-        for (int i = 0; i < HE; i++) a1[i] *= act1_from_value<ACT>(h1[i]);
+            for (int q = 0; q < HE * NCH; q++) {
+                const int j = q / NCH, part = q % NCH;
+                if (q + 1 < HE * NCH) {
+#pragma unroll
+                    for (int p = 0; p < CP; p++)
+                        wn[p] = make2<T>(T(th[Lo.WE2() + (q + 1) * CH + 2 * p]),
+                                         T(th[Lo.WE2() + (q + 1) * CH + 2 * p + 1]));
+                }
+                PINN_ROW_FENCE();
+                const V xs = splat2<T>(a2[j]);
+#pragma unroll
+                for (int p = 0; p < CP; p++) {
+                    A1[part * CP + p] += wc[p] * xs;
+                    PINN_PIN(A1[part * CP + p]);
+                }
+                PINN_ROW_FENCE();
+#pragma unroll
+                for (int p = 0; p < CP; p++) wc[p] = wn[p];
+            }
+#pragma unroll
+            for (int i = 0; i < HE; i++) a1[i] = A1[i >> 1][i & 1] * act1_from_value<ACT>(h1[i]);
+        }
         sink.e1(a1, R);           // WE1-bar = a1*R, bE1-bar = a1
         T tg[HG], ag[HG];
+        {
+            T wg2[HG];
 #pragma unroll
-        for (int j = 0; j < HG; j++) {
-            tg[j] = gb * hg[j];
-            ag[j] = gb * T(th[Lo.WG2() + j]) * act1_from_value<ACT>(hg[j]);
+            for (int j = 0; j < HG; j++) wg2[j] = T(th[Lo.WG2() + j]);
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < HG; j++) {
+                tg[j] = gb * hg[j];
+                ag[j] = gb * wg2[j] * act1_from_value<ACT>(hg[j]);
+            }
+            PINN_ROW_FENCE();
         }
         sink.g2(tg, gb);          // WG2-bar, bG2-bar
         sink.g1(ag, R);           // WG1-bar = ag*R, bG1-bar = ag

@@ -77,8 +77,17 @@ static void run(const double* theta_d, const double* x, const double* y, const d
     using Lay = TrunkLayout<H, L>;
     const RnetLayout RL{HE, HG};
     const int P = Lay::size + RL.size();
-    std::vector<T> th(P);
-    for (int i = 0; i < P; i++) th[i] = T(theta_d[i]);
+    std::vector<T> th(P), thT(P);
+    for (int i = 0; i < P; i++) th[i] = thT[i] = T(theta_d[i]);
+    // thT: forward-contracted matrices stored input-major (same rule as k_prep_theta)
+    for (int j = 0; j < H; j++)
+        for (int c = 0; c < 2; c++) thT[Lay::W(0) + c * H + j] = th[Lay::W(0) + 2 * j + c];
+    for (int l = 1; l < L; l++)
+        for (int j = 0; j < H; j++)
+            for (int i = 0; i < H; i++) thT[Lay::W(l) + i * H + j] = th[Lay::W(l) + j * H + i];
+    for (int j = 0; j < HE; j++)
+        for (int i = 0; i < HE; i++)
+            thT[Lay::size + RL.WE2() + i * HE + j] = th[Lay::size + RL.WE2() + j * HE + i];
     std::memset(grad, 0, sizeof(double) * P);
     HostSink<H, L, HE, HG, T> sink{grad};
     double S0 = 0, S1 = 0, S2 = 0;
@@ -93,13 +102,13 @@ static void run(const double* theta_d, const double* x, const double* y, const d
         T F = in[0][0][0] + Pw * in[0][1][0], lapF = in[0][0][4] + Pw * in[0][1][4];
         Rnet<HE, HG, ACT, T> rn;
         T E, g;
-        rn.forward(th.data() + Lay::size, Rv, E, g);
+        rn.forward(th.data() + Lay::size, thT.data() + Lay::size, Rv, E, g);
         TrunkPass<H, L, ACT, T> pass[2];
         T Sv = 0, Sl = 0;
-        pass[0].forward(th.data(), in[0], Sv, Sl);
+        pass[0].forward(th.data(), thT.data(), in[0], Sv, Sl);
         if (A.n_pass == 2) {
             T Sv2 = 0, Sl2 = 0;
-            pass[1].forward(th.data(), in[1], Sv2, Sl2);
+            pass[1].forward(th.data(), thT.data(), in[1], Sv2, Sl2);
             Sv += Pw * Sv2;
             Sl += Pw * Sl2;
         }
@@ -111,8 +120,8 @@ static void run(const double* theta_d, const double* x, const double* y, const d
                 T(A.invN1), T(A.invN2), T(1), t);
         S0 += t.l_pde; S1 += t.l_bc1; S2 += t.l_bc2;
         if (psi) { psi[k] = t.psi; lap[k] = t.lap; res[k] = t.res; Eo[k] = E; }
-        pass[0].backward(th.data(), in[0], os * t.Nb, os * t.lapNb, sink);
-        if (A.n_pass == 2) pass[1].backward(th.data(), in[1], os * Pw * t.Nb, os * Pw * t.lapNb, sink);
+        pass[0].backward(th.data(), thT.data(), in[0], os * t.Nb, os * t.lapNb, sink);
+        if (A.n_pass == 2) pass[1].backward(th.data(), thT.data(), in[1], os * Pw * t.Nb, os * Pw * t.lapNb, sink);
         grad[Lay::bout] += t.Nb;
         rn.backward(th.data() + Lay::size, Rv, t.Eb, t.gb, sink);
     }

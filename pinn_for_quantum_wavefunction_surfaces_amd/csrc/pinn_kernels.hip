@@ -162,10 +162,11 @@ struct TrunkSink {
     float* U;
     float* V;
     int lane;
-    f32x4 tW[L - 1][HT][HT];  // W_l-bar, l = 1..L-1
-    f32x4 tB[L - 1][HT];      // col 0: b_l-bar
-    f32x4 tW0[HT];            // cols 0,1: W_0-bar; col 2: b_0-bar
-    f32x4 tOut[HT];           // col 0: wout-bar
+    f32x4 tW[L - 1][HT][HT];  // W_l-bar (l = 1..L-1): contraction over the wave's points on the MFMA pipe
+    // vector gradients: lane-local running sums over this lane's points, reduced once at the end
+    float accB[L][H];         // b_l-bar
+    float accW0[H][2];        // W_0-bar
+    float accOut[H];          // wout-bar
 
     __device__ __forceinline__ void zero()
     {
@@ -173,27 +174,23 @@ struct TrunkSink {
 #pragma unroll
         for (int l = 0; l < L - 1; l++)
 #pragma unroll
-            for (int a = 0; a < HT; a++) {
-                tB[l][a] = z;
+            for (int a = 0; a < HT; a++)
 #pragma unroll
                 for (int b = 0; b < HT; b++) tW[l][a][b] = z;
-            }
 #pragma unroll
-        for (int a = 0; a < HT; a++) { tW0[a] = z; tOut[a] = z; }
+        for (int j = 0; j < H; j++) {
+#pragma unroll
+            for (int l = 0; l < L; l++) accB[l][j] = 0.f;
+            accW0[j][0] = 0.f;
+            accW0[j][1] = 0.f;
+            accOut[j] = 0.f;
+        }
     }
 
     __device__ __forceinline__ void out_weight(const float (&t)[H])
     {
-        stage_rows<H>(U, 0, t, lane);
-        wave_lds_sync();
-        Frag one;
-        const_frag(0, 1.0f, lane, one);
 #pragma unroll
-        for (int a = 0; a < HT; a++) {
-            Frag fa;
-            load_frag(U, a, lane, fa);
-            mma(tOut[a], fa, one);
-        }
+        for (int j = 0; j < H; j++) accOut[j] += t[j];
     }
 
     __device__ __forceinline__ void weight(int l, int s, const float (&ab)[H], const float (&oin)[H])
@@ -212,63 +209,56 @@ struct TrunkSink {
             for (int a = 0; a < HT; a++) mma(tW[l - 1][a][b], fa[a], fb);
         }
         if (s == 0) {
-            Frag one;
-            const_frag(0, 1.0f, lane, one);
 #pragma unroll
-            for (int a = 0; a < HT; a++) mma(tB[l - 1][a], fa[a], one);
+            for (int j = 0; j < H; j++) accB[l][j] += ab[j];
         }
     }
 
     __device__ __forceinline__ void weight0(int s, const float (&ab)[H], float in0, float in1)
     {
-        stage_rows<H>(U, 0, ab, lane);
-        stage_row(V, 0, in0, lane);
-        stage_row(V, 1, in1, lane);
-        stage_row(V, 2, s == 0 ? 1.0f : 0.0f, lane);
-        wave_lds_sync();
-        Frag fb;
-        load_frag(V, 0, lane, fb);  // rows 3..15 hold stale finite data: unused columns
 #pragma unroll
-        for (int a = 0; a < HT; a++) {
-            Frag fa;
-            load_frag(U, a, lane, fa);
-            mma(tW0[a], fa, fb);
+        for (int j = 0; j < H; j++) {
+            accW0[j][0] += ab[j] * in0;
+            accW0[j][1] += ab[j] * in1;
+            if (s == 0) accB[0][j] += ab[j];
         }
     }
 
-    // add this wave's tiles into the block gradient image g (theta order)
+    // add this wave's contribution into the block gradient image g (theta order)
     __device__ __forceinline__ void dump(float* g, bool add)
     {
         using Lay = TrunkLayout<H, L>;
 #pragma unroll
         for (int l = 1; l < L; l++)
 #pragma unroll
-            for (int a = 0; a < HT; a++) {
+            for (int a = 0; a < HT; a++)
 #pragma unroll
                 for (int b = 0; b < HT; b++)
                     tile_store(tW[l - 1][a][b], g + Lay::W(l) + (16 * a) * H + 16 * b, H, 1, 16, 16,
                                lane, add);
-                tile_store(tB[l - 1][a], g + Lay::b(l) + 16 * a, 1, 0, 16, 1, lane, add);
-            }
 #pragma unroll
-        for (int a = 0; a < HT; a++) {
-            tile_store(tW0[a], g + Lay::W(0) + (16 * a) * 2, 2, 1, 16, 2, lane, add);
-            // column 2 of tW0 is the layer-0 bias
-            {
-                const int c = lane & 15, gq = lane >> 4;
-                if (c == 2) {
+        for (int j = 0; j < H; j++) {
+            float v[L + 3];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float* p = g + Lay::b(0) + 16 * a + 4 * gq + r;
-                        *p = add ? *p + tW0[a][r] : tW0[a][r];
-                    }
+            for (int l = 0; l < L; l++) v[l] = wave_sum(accB[l][j]);
+            v[L] = wave_sum(accW0[j][0]);
+            v[L + 1] = wave_sum(accW0[j][1]);
+            v[L + 2] = wave_sum(accOut[j]);
+            if (lane == 0) {
+#pragma unroll
+                for (int l = 0; l < L; l++) {
+                    float* p = g + Lay::b(l) + j;
+                    *p = add ? *p + v[l] : v[l];
                 }
+                float* p0 = g + Lay::W(0) + 2 * j;
+                p0[0] = add ? p0[0] + v[L] : v[L];
+                p0[1] = add ? p0[1] + v[L + 1] : v[L + 1];
+                float* po = g + Lay::Wout + j;
+                *po = add ? *po + v[L + 2] : v[L + 2];
             }
-            tile_store(tOut[a], g + Lay::Wout + 16 * a, 1, 0, 16, 1, lane, add);
         }
     }
 };
-
 
 // one wave per SIMD: the packed rank-1 formulation keeps ~300 values live; at the 256-register
 // cap of two waves it spills 700 B/lane and runs 1.4x slower (VALU throughput does not depend on
@@ -518,8 +508,10 @@ struct RnetSink {
     }
 };
 
+// two waves per SIMD: the 32-wide mat-vecs do only 8 packed FMAs per 16-float weight chunk, so a
+// second wave is what hides the scalar-load latency (1 wave/SIMD measured 1.8x slower)
 template <int HE, int HG, int ACT>
-__global__ __launch_bounds__(kBlock) void k_rnet_bwd(const float* __restrict__ th_r,
+__global__ __launch_bounds__(kBlock, 2) void k_rnet_bwd(const float* __restrict__ th_r,
                                                      const float* __restrict__ thT_r,
                                                      const float* __restrict__ R,
                                                      const float* __restrict__ Eb,

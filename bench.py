@@ -96,9 +96,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PINN_FORCE_DIST") == "1"   # the latter: RCCL sanity at N=1
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -116,26 +118,39 @@ def main():
         w = np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))
         model.load_flat_params(torch.tensor(w["ionHsym"]))
     theta0 = model.flat_params(dtype=torch.float64).cpu().numpy()
-    plan = pkg.DataParallelPlan(args.points, rank=rank, world=world)
-    tr = pkg.Trainer(model, params, n_points=args.points, lr=8e-3, seed=12345, device=dev, plan=plan)
-    tr.h.profile_enable(min(max(args.steps, 1), 1024))
+    plan = pkg.DataParallelPlan(args.points, rank=rank, world=world, force_collectives=use_dist)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tr.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step()
-    barrier()
-    dt = plan.max_over_ranks(time.perf_counter() - t0, dev)
-    trunk_ms = tr.h.profile_read(min(args.steps, 1024))
-    Ltot, Lpde, Lbc = tr.losses()
+    def run(model, arch_name):
+        """W untimed + K timed steps of one workload; returns (seconds, trunk kernel ms, losses)"""
+        tr = pkg.Trainer(model, params, n_points=args.points, lr=8e-3, seed=12345, device=dev, plan=plan)
+        tr.h.profile_enable(min(max(args.steps, 1), 1024))
+        for _ in range(args.warmup):
+            tr.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step()
+        barrier()
+        dt = plan.max_over_ranks(time.perf_counter() - t0, dev)
+        return dt, tr.h.profile_read(min(args.steps, 1024)), tr.losses()
+
+    dt, trunk_ms, (Ltot, Lpde, Lbc) = run(model, args.arch)
+    # the other workload rides along as a secondary record (same K, W, points)
+    other = "ref16" if args.arch != "ref16" else "wide64"
+    oarch = ARCHS[other]
+    torch.manual_seed(12345)
+    omodel = pkg.NN_ion(params, oarch["H"], oarch["HE"], oarch["HG"], n_hidden=oarch["L"],
+                        act=oarch["act_name"], precision=oarch["precision"]).to(dev)
+    if other == "ref16":
+        omodel.load_flat_params(torch.tensor(
+            np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))["ionHsym"]))
+    odt, otrunk_ms, olosses = run(omodel, other)
 
     if rank == 0:
         n_total = args.points * world
@@ -168,10 +183,19 @@ def main():
                                   "bf16 dense MFMA peak; algorithmic trunk flops only")},
             "loss": {"Ltot": Ltot, "Lpde": Lpde, "Lbc": Lbc},
         }
+        ofl = trunk_flops_per_point(oarch["H"], oarch["L"], oarch["n_pass"])
+        oach = ofl * args.points / (otrunk_ms * 1e-3) / 1e12
+        out["secondary"] = {"workload": oarch["label"], "arch": other, "dtype": oarch["dtype"],
+                            "value": n_total * args.steps / odt, "unit": "points/s",
+                            "ms_per_step": odt / args.steps * 1e3,
+                            "roofline": {"bound": "mfma", "achieved": oach, "peak": oarch["peak"],
+                                         "unit": "TFLOP/s", "frac": oach / oarch["peak"],
+                                         "kernel_ms": otrunk_ms, "flops_per_point": ofl},
+                            "loss": {"Ltot": olosses[0]}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(theta0, arch)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -15,12 +15,14 @@ import torch.distributed as dist
 
 
 class DataParallelPlan:
-    def __init__(self, n_local, rank=None, world=None, group=None):
+    def __init__(self, n_local, rank=None, world=None, group=None, force_collectives=False):
         if world is None:
             world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         if rank is None:
             rank = dist.get_rank(group) if world > 1 else 0
         self.n_local, self.rank, self.world, self.group = int(n_local), int(rank), int(world), group
+        # world == 1 normally skips the collectives; forcing them exercises the RCCL path on one GPU
+        self.collectives = self.world > 1 or bool(force_collectives)
 
     @property
     def first(self):
@@ -37,18 +39,18 @@ class DataParallelPlan:
 
     def reduce_counts(self, counts):
         """int64[2] BC set sizes: local -> global (in place)."""
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
         return counts
 
     def reduce_grad(self, buf):
         """fp32[P+3] = [grad | three loss terms]: local partial -> global (in place)."""
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return buf
 
     def max_over_ranks(self, seconds, device):
         t = torch.tensor([seconds], dtype=torch.float64, device=device)
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())

@@ -350,3 +350,45 @@ def test_mfma_bf16_tanh_single_pass_matches_oracle():
     mask = ((np.sqrt((x - R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8)
             + 2 * (np.sqrt((x + R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8))
     _mfma_case(theta, x, y, z, R, mask, 1, "B", A, O.ham_B())
+
+
+def test_fine_tune_mode_trains_only_the_E_net(golden_dir):
+    """config 4's recipe (poc/main.py:932-942): warm start from ionHsym, trunk + gate frozen,
+    lr 5e-4, R in [0.5, 4]: E-net parameters move, everything else stays bit-identical"""
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))["ionHsym"]
+    params = pkg.set_params()
+    params["RxL"] = 0.5
+    model = pkg.NN_ion(params).to(DEV)
+    model.load_flat_params(torch.tensor(w))
+    model.freezeDecayUnit()
+    model.freezeBase()
+    tr = pkg.Trainer(model, params, n_points=100000, lr=5e-4, device=DEV)
+    th0 = tr.theta.clone()
+    tr.step()
+    l0 = tr.losses()[0]
+    for _ in range(40):
+        tr.step()
+    l1 = tr.losses()[0]
+    arch = model.arch
+    off, sz = capi.tensor_layout(arch)
+    th1 = tr.theta
+    for t in range(16):
+        same = torch.equal(th0[off[t]:off[t] + sz[t]], th1[off[t]:off[t] + sz[t]])
+        assert same == (t < 6 or t >= 12), t
+    assert np.isfinite(l1) and l1 < 5 * l0
+    tr.sync_to_model(best=True)
+    assert torch.isfinite(model.flat_params()).all()
+
+
+def test_reference_style_train_driver_runs(tmp_path):
+    """train(params, ...) mirror of poc/main.py:359-430: history schema and decreasing loss"""
+    params = pkg.set_params()
+    params.update(epochs=60, n_train=20000, lossPath=str(tmp_path / "loss.pkl"))
+    torch.manual_seed(0)
+    model, hist = pkg.train(params, verbose=False)
+    assert set(hist) == {"Ltot", "Lbc", "Lpde", "Energy"}
+    assert all(v.shape == (60, 1) and v.dtype == np.float64 for v in hist.values())
+    assert np.allclose(hist["Ltot"], hist["Lpde"] + hist["Lbc"], rtol=1e-5)
+    assert hist["Ltot"][-1, 0] < 0.5 * hist["Ltot"][0, 0]
+    pkg.saveLoss(params, hist)
+    assert os.path.getsize(params["lossPath"]) > 0

@@ -30,6 +30,7 @@
 // tests/test_gpu_parity.py; this path is NOT the 1e-5 parity path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pinn_math.h"
 #include "pinn_common.h"
@@ -569,6 +570,520 @@ __global__ __launch_bounds__(kBlock, 1) void k_trunk_mfma(const float* __restric
     if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
 }
 
+// =====================================================================================
+// Second generation: the 16-point tile of a "group" is shared by SPLIT waves, each owning
+// 32 neurons (two row tiles = one k-chunk).  Per-wave state shrinks by SPLIT, so H = 64 runs
+// two waves per SIMD (latency hiding) and H = 128 fits at all.  Waves of a group exchange
+// B fragments (layer outputs, adjoints) through LDS exchange buffers
+//     EB[(kc*5 + s)*64 + lane]   (16 bytes per lane, lane-linear: conflict-free b128)
+// which every wave of the group reads directly as MFMA B operands, and which double as the
+// [column][neuron] image of the weight-gradient contraction (ds_read_b64_tr_b16 straight
+// from the exchange buffer: no extra image writes).  Workgroup barriers separate the
+// exchange steps; all groups of a block run the same trip count so barriers always match.
+template <int H, int L, int SPLIT, int WAVES>
+struct M2Cfg {
+    static constexpr int HT = H / 16, KC = H / 32, NW = L - 1;
+    static constexpr int GROUPS = WAVES / SPLIT;
+    static_assert(H / SPLIT == 32, "each wave owns 32 neurons");
+    static constexpr int WPK = NW * 2 * H * H;                    // bf16 elements
+    static constexpr int NSMALL = 3 * H + NW * H + H + 4;         // floats
+    static constexpr int EB = KC * 5 * 64 * 16;                   // bytes of one exchange buffer
+    static constexpr int SBYTES = SPLIT * 16 * 2 * 4;             // per-group partial (Sv, Sl)
+    static constexpr int GBYTES = (L - 1) * EB + EB + SBYTES;     // XB[0..L-2], YB, S
+    static constexpr int ZBYTES = 1024;
+    static constexpr size_t OFF_SMALL = (size_t)WPK * 2;
+    static constexpr size_t OFF_ZERO = OFF_SMALL + NSMALL * 4;
+    static constexpr size_t OFF_GRP = OFF_ZERO + ZBYTES;
+    static constexpr size_t LDS_BYTES = OFF_GRP + (size_t)GROUPS * GBYTES;
+};
+
+template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const float* __restrict__ theta,
+                                                                      const __bf16* __restrict__ wpk_g,
+                                                                      TrunkArgs A)
+{
+    using C = M2Cfg<H, L, SPLIT, WAVES>;
+    using Lay = TrunkLayout<H, L>;
+    constexpr int HT = C::HT, KC = C::KC, NW = C::NW, NT = WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* wpk = reinterpret_cast<__bf16*>(lds_raw);
+    float* small = reinterpret_cast<float*>(lds_raw + C::OFF_SMALL);
+    float* sW0 = small;
+    float* sb0 = small + 2 * H;
+    float* sbl = small + 3 * H;
+    float* swo = small + 3 * H + NW * H;
+    float* sbo = swo + H;
+    unsigned char* zero = lds_raw + C::OFF_ZERO;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave / SPLIT, part = wave % SPLIT;
+    const int g = lane >> 4, c = lane & 15;
+    unsigned char* gbase = lds_raw + C::OFF_GRP + (size_t)grp * C::GBYTES;
+    unsigned char* XB = gbase;                          // [(L-1)] exchange buffers: outputs of layers 0..L-2
+    unsigned char* YB = gbase + (size_t)(L - 1) * C::EB; // adjoint exchange buffer
+    float* SB = reinterpret_cast<float*>(YB + C::EB);   // [SPLIT][16][2]
+
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(wpk_g);
+        uint4* dst = reinterpret_cast<uint4*>(wpk);
+        for (int k = threadIdx.x; k < C::WPK / 8; k += NT) dst[k] = src[k];
+        for (int k = threadIdx.x; k < 2 * H; k += NT) sW0[k] = theta[Lay::W(0) + k];
+        for (int k = threadIdx.x; k < H; k += NT) {
+            sb0[k] = theta[Lay::b(0) + k];
+            swo[k] = theta[Lay::Wout + k];
+#pragma unroll
+            for (int l = 1; l < L; l++) sbl[(l - 1) * H + k] = theta[Lay::b(l) + k];
+        }
+        if (threadIdx.x == 0) sbo[0] = theta[Lay::bout];
+        for (int k = threadIdx.x; k < C::ZBYTES / 4; k += NT) reinterpret_cast<unsigned*>(zero)[k] = 0u;
+    }
+    __syncthreads();
+
+    // ---- persistent gradient state (own 32 neurons = row tiles 2*part, 2*part+1)
+    f32x4 wacc[NW][2][HT];
+    f32x4 bacc[L][2], w0acc[2][2], woacc[2];
+    float acc_bout = 0.f, acc_pde = 0.f, acc_bc1 = 0.f, acc_bc2 = 0.f;
+    if (MODE == MODE_BWD) {
+#pragma unroll
+        for (int l = 0; l < NW; l++)
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int b = 0; b < HT; b++) wacc[l][t][b] = splat(0.f);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+#pragma unroll
+            for (int l = 0; l < L; l++) bacc[l][t] = splat(0.f);
+            w0acc[t][0] = splat(0.f); w0acc[t][1] = splat(0.f); woacc[t] = splat(0.f);
+        }
+    }
+    float invN1 = A.invN1, invN2 = A.invN2;
+    if (MODE != MODE_FWD && A.bc_counts) {
+        const long long c1 = A.bc_counts[0], c2 = A.bc_counts[1];
+        invN1 = c1 > 0 ? 1.0f / (float)c1 : 0.0f;
+        invN2 = c2 > 0 ? 1.0f / (float)c2 : 0.0f;
+    }
+    // per-point sums are taken by ONE lane group of ONE wave of the group
+    const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
+    const int64_t ntile = (A.n + 15) / 16;
+    const int64_t tstride = (int64_t)gridDim.x * C::GROUPS;
+    const int64_t iters = (ntile + tstride - 1) / tstride;   // same for every wave: barriers match
+
+    for (int64_t itx = 0; itx < iters; itx++) {
+        const int64_t tile = itx * tstride + (int64_t)blockIdx.x * C::GROUPS + grp;
+        const int64_t idx = tile * 16 + c;
+        const bool valid = tile < ntile && idx < A.n;
+        const int64_t id = valid ? idx : A.n - 1;
+        const float xv = A.x[id], yv = A.y[id], zv = A.z[id], Rv = A.R[id];
+        const float Ev = A.E[id], gv = A.g[id];
+        float m1 = 0.f, m2 = 0.f;
+        if (MODE != MODE_FWD && A.mask) {
+            const uint8_t mk = A.mask[id];
+            m1 = float(mk & 1);
+            m2 = float((mk >> 1) & 1);
+        }
+        float inA[2][5], ri1, ri2;
+        orbital<float>(xv - Rv, yv, zv, inA[0], ri1);
+        orbital<float>(xv + Rv, yv, zv, inA[1], ri2);
+        const float F = inA[0][0] + A.P * inA[1][0];
+        const float lapF = inA[0][4] + A.P * inA[1][4];
+
+        Tail<float> t;
+        float SvA = 0.f, SlA = 0.f;
+        constexpr int nstage = NPASS == 2 ? (MODE == MODE_BWD ? 3 : 2) : 1;
+#pragma unroll 1
+        for (int st = 0; st < nstage; st++) {
+            const bool useB = NPASS == 2 && st == 1;
+            float in[2][5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                in[0][s] = useB ? inA[1][s] : inA[0][s];
+                in[1][s] = useB ? inA[0][s] : inA[1][s];
+            }
+            // =========================== forward ===========================
+            u32x2 sv[NW][2][5];  // saved (h, a_x, a_y, a_z, a_lap) of the own neurons, layers 1..L-1
+            {   // ---- layer 0 on the VALU (K = 2), own neurons only
+                u32x4 xo[5];
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) {
+                    const int n0 = 32 * part + 16 * tt + 4 * g;
+                    const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2);
+                    const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2 + 4);
+                    const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb0 + n0);
+                    f32x4 a[5];
+#pragma unroll
+                    for (int s = 0; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
+                    a[0] += b0;
+                    f32x4 s0, s1, s2;
+                    act012v<ACT>(a[0], s0, s1, s2);
+                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                    f32x4 o[5] = {s0, s1 * a[1], s1 * a[2], s1 * a[3], s1 * a[4] + s2 * q};
+#pragma unroll
+                    for (int s = 0; s < 5; s++) {
+                        const u32x2 p = pack4(o[s]);
+                        if (tt) { xo[s][2] = p[0]; xo[s][3] = p[1]; }
+                        else { xo[s][0] = p[0]; xo[s][1] = p[1]; }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 5; s++)
+                    *reinterpret_cast<u32x4*>(XB + ((size_t)(part * 5 + s) * 64 + lane) * 16) = xo[s];
+            }
+            __syncthreads();
+            float Sv = 0.f, Sl = 0.f;
+#pragma unroll
+            for (int l = 1; l < L; l++) {
+                const __bf16* wf = wpk + (size_t)((l - 1) * 2 + 0) * H * H;
+                const unsigned char* xin = XB + (size_t)(l - 1) * C::EB;
+                f32x4 a[2][5];
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) {
+                    a[tt][0] = *reinterpret_cast<const f32x4*>(sbl + (l - 1) * H + 32 * part + 16 * tt + 4 * g);
+#pragma unroll
+                    for (int s = 1; s < 5; s++) a[tt][s] = splat(0.f);
+                }
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++) {
+                    bf16x8 wa[2];
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++)
+                        wa[tt] = *reinterpret_cast<const bf16x8*>(wf + (((2 * part + tt) * KC + kc) * 64 + lane) * 8);
+#pragma unroll
+                    for (int s = 0; s < 5; s++) {
+                        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xin + ((size_t)(kc * 5 + s) * 64 + lane) * 16);
+#pragma unroll
+                        for (int tt = 0; tt < 2; tt++) a[tt][s] = mfma(wa[tt], xb, a[tt][s]);
+                    }
+                }
+                u32x4 xo[5];
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) {
+                    f32x4 s0, s1, s2;
+                    act012v<ACT>(a[tt][0], s0, s1, s2);
+                    const f32x4 q = a[tt][1] * a[tt][1] + a[tt][2] * a[tt][2] + a[tt][3] * a[tt][3];
+                    const f32x4 ol = s1 * a[tt][4] + s2 * q;
+                    sv[l - 1][tt][0] = pack4(s0);
+#pragma unroll
+                    for (int s = 1; s < 5; s++) sv[l - 1][tt][s] = pack4(a[tt][s]);
+                    if (l < L - 1) {
+                        f32x4 o[5] = {s0, s1 * a[tt][1], s1 * a[tt][2], s1 * a[tt][3], ol};
+#pragma unroll
+                        for (int s = 0; s < 5; s++) {
+                            const u32x2 p = pack4(o[s]);
+                            if (tt) { xo[s][2] = p[0]; xo[s][3] = p[1]; }
+                            else { xo[s][0] = p[0]; xo[s][1] = p[1]; }
+                        }
+                    } else {
+                        const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 32 * part + 16 * tt + 4 * g);
+                        const f32x4 pv = wo * s0, pl = wo * ol;
+                        Sv += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                        Sl += (pl[0] + pl[1]) + (pl[2] + pl[3]);
+                    }
+                }
+                if (l < L - 1) {
+                    unsigned char* xout = XB + (size_t)l * C::EB;
+#pragma unroll
+                    for (int s = 0; s < 5; s++)
+                        *reinterpret_cast<u32x4*>(xout + ((size_t)(part * 5 + s) * 64 + lane) * 16) = xo[s];
+                    __syncthreads();
+                }
+            }
+            // ---- combine the partial output sums of the group's waves (fixed order)
+            Sv = xg_sum(Sv);
+            Sl = xg_sum(Sl);
+            if (g == 0) { SB[(part * 16 + c) * 2] = Sv; SB[(part * 16 + c) * 2 + 1] = Sl; }
+            __syncthreads();
+            Sv = 0.f; Sl = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < SPLIT; pp++) { Sv += SB[(pp * 16 + c) * 2]; Sl += SB[(pp * 16 + c) * 2 + 1]; }
+            const bool do_tail = NPASS == 1 || st == 1;
+            if (NPASS == 2 && st == 0) { SvA = Sv; SlA = Sl; }
+            if (do_tail) {
+                if (NPASS == 2) { Sv = SvA + A.P * Sv; Sl = SlA + A.P * Sl; }
+                const float N = A.out_scale * Sv + sbo[0];
+                const float lapN = A.out_scale * Sl;
+                tail<float>(N, lapN, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1, m2, A.invN, invN1,
+                            invN2, valid ? 1.0f : 0.0f, t);
+                if (MODE == MODE_FWD) {
+                    if (valid && g == 0 && part == 0) {
+                        if (A.psi) A.psi[idx] = t.psi;
+                        if (A.lap) A.lap[idx] = t.lap;
+                        if (A.res) A.res[idx] = t.res;
+                    }
+                } else {
+                    if (valid && g == 0 && part == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+                    acc_pde += lead * t.l_pde;
+                    acc_bc1 += lead * t.l_bc1;
+                    acc_bc2 += lead * t.l_bc2;
+                    acc_bout += lead * t.Nb;
+                }
+            }
+            if (!(MODE == MODE_BWD && (NPASS == 1 || st >= 1))) continue;   // uniform over the block
+            // =========================== reverse ===========================
+            const float pw = useB ? A.P : 1.0f;
+            const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
+            {   // ---- last hidden layer, own neurons
+                u32x4 yo[5];
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) {
+                    const f32x4 h = unpack4(sv[NW - 1][tt][0]);
+                    f32x4 a[5];
+#pragma unroll
+                    for (int s = 1; s < 5; s++) a[s] = unpack4(sv[NW - 1][tt][s]);
+                    f32x4 s1, s2, s3;
+                    act123v<ACT>(h, s1, s2, s3);
+                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                    const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 32 * part + 16 * tt + 4 * g);
+                    woacc[tt] += cv * h + cl * (s1 * a[4] + s2 * q);
+                    const f32x4 o0 = cv * wo, ol = cl * wo;
+                    const f32x4 u = 2.0f * s2 * ol;
+                    f32x4 ab[5];
+                    ab[4] = s1 * ol;
+                    ab[1] = u * a[1];
+                    ab[2] = u * a[2];
+                    ab[3] = u * a[3];
+                    ab[0] = s1 * o0 + (s2 * a[4] + s3 * q) * ol;
+                    bacc[L - 1][tt] += ab[0];
+#pragma unroll
+                    for (int s = 0; s < 5; s++) {
+                        const u32x2 p = pack4(ab[s]);
+                        if (tt) { yo[s][2] = p[0]; yo[s][3] = p[1]; }
+                        else { yo[s][0] = p[0]; yo[s][1] = p[1]; }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 5; s++)
+                    *reinterpret_cast<u32x4*>(YB + ((size_t)(part * 5 + s) * 64 + lane) * 16) = yo[s];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int l = L - 1; l >= 1; l--) {
+                const unsigned char* xin = XB + (size_t)(l - 1) * C::EB;
+                // ---- W_l-bar[own rows][all columns] += Y-bar (x) X, 32 of the 80 columns per phase,
+                //      both operands read transposed straight out of the exchange buffers
+#pragma unroll
+                for (int ph = 0; ph < 3; ph++) {
+                    // rows k = 8g + 4hh + (c>>2) of the phase: stream 2ph + (k>>4), point k&15
+                    const unsigned char* ay[2];
+                    const unsigned char* ax[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        const int k = 8 * g + 4 * hh + (c >> 2);
+                        const int s = 2 * ph + (k >> 4), cc = k & 15;
+                        const bool pad = s > 4;  // phase 2, upper 16 rows: zeros
+                        const size_t rowoff = ((size_t)(s > 4 ? 0 : s) * 64 + cc) * 16 + (c & 1) * 8;
+                        ay[hh] = pad ? zero : YB + rowoff;   // + (kc*5*64 + gsel*16)*16 per tile below
+                        ax[hh] = pad ? zero : xin + rowoff;
+                    }
+                    const size_t chunk = (size_t)((c & 3) >> 1) * 16 * 16;  // slot group within the tile
+                    bf16x8 fx[HT];
+#pragma unroll
+                    for (int it = 0; it < HT; it++) {
+                        const size_t toff = ((size_t)(it >> 1) * 5 * 64 + (size_t)(2 * (it & 1)) * 16) * 16 + chunk;
+                        const bool z0 = ax[0] == zero, z1 = ax[1] == zero;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(z0 ? zero : ax[0] + toff));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(z1 ? zero : ax[1] + toff));
+                        fx[it] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++) {
+                        const int T = 2 * part + tt;
+                        const size_t toff = ((size_t)(T >> 1) * 5 * 64 + (size_t)(2 * (T & 1)) * 16) * 16 + chunk;
+                        const bool z0 = ay[0] == zero, z1 = ay[1] == zero;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(z0 ? zero : ay[0] + toff));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(z1 ? zero : ay[1] + toff));
+                        const bf16x8 fy = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                        for (int it = 0; it < HT; it++) wacc[l - 1][tt][it] = mfma(fy, fx[it], wacc[l - 1][tt][it]);
+                    }
+                }
+                // ---- adjoint of layer l's input for the own neurons, then layer l-1's activation adjoint
+                const __bf16* wb = wpk + (size_t)((l - 1) * 2 + 1) * H * H;
+                f32x4 ob[2][5];
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int s = 0; s < 5; s++) ob[tt][s] = splat(0.f);
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++) {
+                    bf16x8 wa[2];
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++)
+                        wa[tt] = *reinterpret_cast<const bf16x8*>(wb + (((2 * part + tt) * KC + kc) * 64 + lane) * 8);
+#pragma unroll
+                    for (int s = 0; s < 5; s++) {
+                        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(YB + ((size_t)(kc * 5 + s) * 64 + lane) * 16);
+#pragma unroll
+                        for (int tt = 0; tt < 2; tt++) ob[tt][s] = mfma(wa[tt], yb, ob[tt][s]);
+                    }
+                }
+                u32x4 yo[5];
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) {
+                    f32x4 h, a[5];
+                    if (l - 1 == 0) {
+                        const int n0 = 32 * part + 16 * tt + 4 * g;
+                        const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2);
+                        const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2 + 4);
+                        const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
+#pragma unroll
+                        for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
+                        const u32x4 hx = *reinterpret_cast<const u32x4*>(XB + ((size_t)(part * 5 + 0) * 64 + lane) * 16);
+                        h = unpack4(tt ? u32x2{hx[2], hx[3]} : u32x2{hx[0], hx[1]});
+                    } else {
+                        h = unpack4(sv[l - 2][tt][0]);
+#pragma unroll
+                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[l - 2][tt][s]);
+                    }
+                    f32x4 s1, s2, s3;
+                    act123v<ACT>(h, s1, s2, s3);
+                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                    const f32x4 u = 2.0f * s2 * ob[tt][4];
+                    f32x4 ab[5];
+                    ab[4] = s1 * ob[tt][4];
+                    ab[1] = s1 * ob[tt][1] + u * a[1];
+                    ab[2] = s1 * ob[tt][2] + u * a[2];
+                    ab[3] = s1 * ob[tt][3] + u * a[3];
+                    ab[0] = s1 * ob[tt][0] + s2 * (a[1] * ob[tt][1] + a[2] * ob[tt][2] + a[3] * ob[tt][3]) +
+                            (s2 * a[4] + s3 * q) * ob[tt][4];
+                    bacc[l - 1][tt] += ab[0];
+                    if (l - 1 == 0) {
+                        f32x4 g0 = splat(0.f), g1 = splat(0.f);
+#pragma unroll
+                        for (int s = 0; s < 5; s++) { g0 += ab[s] * in[0][s]; g1 += ab[s] * in[1][s]; }
+                        w0acc[tt][0] += g0;
+                        w0acc[tt][1] += g1;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 5; s++) {
+                            const u32x2 p = pack4(ab[s]);
+                            if (tt) { yo[s][2] = p[0]; yo[s][3] = p[1]; }
+                            else { yo[s][0] = p[0]; yo[s][1] = p[1]; }
+                        }
+                    }
+                }
+                if (l - 1 >= 1) {   // hand the next layer's adjoints to the group
+                    __syncthreads();   // everyone is done reading YB
+#pragma unroll
+                    for (int s = 0; s < 5; s++)
+                        *reinterpret_cast<u32x4*>(YB + ((size_t)(part * 5 + s) * 64 + lane) * 16) = yo[s];
+                    __syncthreads();
+                }
+            }
+            // the next stage (or tile) overwrites the own XB slot, which the other waves of the
+            // group read in their weight-gradient phase: wait until they are through
+            __syncthreads();
+        }
+    }
+
+    if (MODE == MODE_FWD) return;
+    // =========================== block reduction ===========================
+    __syncthreads();
+    constexpr int PT = Lay::size;
+    float* gimg = reinterpret_cast<float*>(lds_raw);
+    float* sc = gimg + PT;
+    const float s0 = row16_sum(xg_sum(acc_pde)), s1r = row16_sum(xg_sum(acc_bc1)),
+                s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
+    if (MODE == MODE_BWD) {
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+#pragma unroll
+                for (int l = 0; l < L; l++) bacc[l][tt][r] = row16_sum(bacc[l][tt][r]);
+                w0acc[tt][0][r] = row16_sum(w0acc[tt][0][r]);
+                w0acc[tt][1][r] = row16_sum(w0acc[tt][1][r]);
+                woacc[tt][r] = row16_sum(woacc[tt][r]);
+            }
+        // zero the image once (each wave only touches its own rows; several groups add into them)
+        for (int k = threadIdx.x; k < PT + 4; k += NT) gimg[k] = 0.f;
+    } else {
+        if (threadIdx.x < 4) sc[threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    for (int w = 0; w < WAVES; w++) {
+        if (wave == w) {
+            if (MODE == MODE_BWD) {
+#pragma unroll
+                for (int l = 1; l < L; l++)
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                        for (int it = 0; it < HT; it++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const int nj = q_neuron(16 * (2 * part + tt) + 4 * g + r), ni = q_neuron(16 * it + c);
+                                gimg[Lay::W(l) + nj * H + ni] += wacc[l - 1][tt][it][r];
+                            }
+                if (c == 0) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int nj = 32 * part + 16 * tt + 4 * g + r;
+#pragma unroll
+                            for (int l = 0; l < L; l++) gimg[Lay::b(l) + nj] += bacc[l][tt][r];
+                            gimg[Lay::W(0) + 2 * nj] += w0acc[tt][0][r];
+                            gimg[Lay::W(0) + 2 * nj + 1] += w0acc[tt][1][r];
+                            gimg[Lay::Wout + nj] += woacc[tt][r];
+                        }
+                }
+            }
+            if (lane == 0) { sc[0] += s0; sc[1] += s1r; sc[2] += s2r; sc[3] += s3r; }
+        }
+        __syncthreads();
+    }
+    float* out = A.partial + (size_t)blockIdx.x * A.stride;
+    if (MODE == MODE_BWD) {
+        for (int k = threadIdx.x; k < PT; k += NT) out[k] = k == Lay::bout ? sc[3] : gimg[k];
+    } else {
+        for (int k = threadIdx.x; k < PT; k += NT) out[k] = 0.0f;
+    }
+    if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
+}
+
+template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES>
+hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
+{
+    using C1 = MCfg<H, L>;
+    using C = M2Cfg<H, L, SPLIT, WAVES>;
+    const int nfrag = C1::NW * 2 * C1::HT * C1::KC * 64;
+    hipLaunchKernelGGL((k_pack_weights<H, L>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    auto kern = k_trunk_mfma2<H, L, ACT, NPASS, MODE, SPLIT, WAVES>;
+    size_t lds = C::LDS_BYTES;
+    const size_t need = (size_t)(TrunkLayout<H, L>::size + 16) * 4;
+    if (lds < need) lds = need;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, theta, (const __bf16*)wpk, A);
+    return hipGetLastError();
+}
+
+template <int H, int L, int SPLIT, int WAVES>
+bool launch2_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, const TrunkArgs& A,
+                int grid, hipStream_t st, hipError_t* e)
+{
+#define PINN_MCASE2(ACT, NP, MD)                                                        \
+    if (act == ACT && npass == NP && mode == MD) {                                      \
+        *e = launch2_t<H, L, ACT, NP, MD, SPLIT, WAVES>(theta, wpk, A, grid, st);        \
+        return true;                                                                    \
+    }
+    PINN_MCASE2(ACT_SIGMOID, 2, MODE_FWD) PINN_MCASE2(ACT_SIGMOID, 2, MODE_BWD)
+    PINN_MCASE2(ACT_SIGMOID, 1, MODE_FWD) PINN_MCASE2(ACT_SIGMOID, 1, MODE_BWD)
+    PINN_MCASE2(ACT_TANH, 2, MODE_FWD) PINN_MCASE2(ACT_TANH, 2, MODE_BWD)
+    PINN_MCASE2(ACT_TANH, 1, MODE_FWD) PINN_MCASE2(ACT_TANH, 1, MODE_BWD)
+#undef PINN_MCASE2
+    return false;
+}
+
 template <int H, int L, int ACT, int NPASS, int MODE>
 hipError_t launch_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
 {
@@ -606,7 +1121,20 @@ bool launch_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, co
 
 }  // namespace
 
-bool mfma_trunk_supported(int H, int L) { return H == 64 && L == 2; }
+bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && L == 2; }
+
+// H = 64 can run either generation.  Measured (1M points, 2x64 tanh, symmetric): point-split
+// 0.90 ms, neuron-split 1.02 ms, so the first generation is the default there; PINN_MFMA_GEN=2
+// selects the neuron-split kernel for A/B measurements.  H = 128 only exists as neuron-split.
+static int mfma_generation()
+{
+    static int gen = -1;
+    if (gen < 0) {
+        const char* e = getenv("PINN_MFMA_GEN");
+        gen = (e && e[0] == '2') ? 2 : 1;
+    }
+    return gen;
+}
 
 size_t mfma_packed_weight_bytes(int H, int L) { return (size_t)(L - 1) * 2 * H * H * 2; }
 
@@ -617,6 +1145,10 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, const float* 
                        hipError_t* err)
 {
     __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
-    if (H == 64 && L == 2) return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
+    if (H == 64 && L == 2) {
+        if (mfma_generation() == 1) return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
+        return launch2_HL<64, 2, 2, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+    }
+    if (H == 128 && L == 2) return launch2_HL<128, 2, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
     return false;
 }

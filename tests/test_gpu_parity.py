@@ -298,12 +298,14 @@ def test_training_reduces_the_loss_and_full_size_properties():
 
 
 # ----------------------------------------------------------------------------- bf16 MFMA path
-# Wide trunk (H = 64) on the matrix cores with bf16 operands.  bf16 cannot meet the 1e-5 bar
-# (SURVEY section 7); the tolerances below are this path's own, stated relative to max-norms:
-#   psi 2e-3, E 1e-5 (E-net stays fp32), lap 1e-2, residual 1e-2, loss 3e-2, gradient 3e-2.
-def _mfma_case(theta, x, y, z, R, mask, act, form, A_or, Hm_or):
+# Wide trunk (H = 64, 128) on the matrix cores with bf16 operands.  bf16 cannot meet the 1e-5
+# bar (bf16 operands alone give psi 6e-4, residual 5e-3, Lpde 1.6e-2 on the
+# reference network); the tolerances below are this path's own, relative to max-norms:
+#   psi 1e-2, E 1e-5 (E-net stays fp32), lap 1e-2, residual 2e-2, loss 3e-2, gradient 3e-2
+# (observed on these cases: psi 1e-4..4e-3, residual 2e-4..5e-3, gradient 2e-3..8e-3).
+def _mfma_case(theta, x, y, z, R, mask, act, form, A_or, Hm_or, H=64):
     f = pkg.model.FORMULATION_A if form == "A" else pkg.model.FORMULATION_B
-    arch = capi.Arch(64, 2, 32, 10, act, f["n_pass"], f["out_scale"], capi.PINN_PREC_BF16)
+    arch = capi.Arch(H, 2, 32, 10, act, f["n_pass"], f["out_scale"], capi.PINN_PREC_BF16)
     h = capi.Handle(arch, 0, 4096)
     fw = O.forward(A_or, Hm_or, theta, x, y, z, R)
     ref = O.loss_grad(A_or, Hm_or, theta, x, y, z, R, mask)
@@ -319,7 +321,7 @@ def _mfma_case(theta, x, y, z, R, mask, act, form, A_or, Hm_or):
         r = ref["grad"][off[t]:off[t] + sz[t]]
         errs["g_" + nm] = np.max(np.abs(out[off[t]:off[t] + sz[t]] - r)) / max(np.max(np.abs(r)), 1e-30)
     print("mfma bf16 errors:", {k: "%.2e" % v for k, v in errs.items()})
-    assert errs["psi"] < 2e-3 and errs["E"] < 1e-5 and errs["lap"] < 1e-2 and errs["res"] < 1e-2
+    assert errs["psi"] < 1e-2 and errs["E"] < 1e-5 and errs["lap"] < 1e-2 and errs["res"] < 2e-2
     assert errs["loss"] < 3e-2 and errs["grad"] < 3e-2
     for nm in names:
         assert errs["g_" + nm] < 6e-2, (nm, errs)
@@ -335,21 +337,24 @@ def test_mfma_bf16_wide_trunk_matches_reference(golden_dir):
                O.arch(H=64), O.ham_A())
 
 
-def test_mfma_bf16_tanh_single_pass_matches_oracle():
-    """the '2x64 tanh' shape, train.py formulation (one pass, 2h): oracle only"""
-    A = O.arch(H=64, act=1, n_pass=1, out_scale=2.0)
-    rng = np.random.default_rng(11)
+@pytest.mark.parametrize("H,form,act", [(64, "B", 1), (128, "A", 0), (128, "B", 1)])
+def test_mfma_bf16_matches_oracle(H, form, act):
+    """wide shapes without a reference vector ('2x64 tanh' in train.py's single-pass form, and
+    2x128 in both formulations on the 4-wave neuron-split kernel): oracle only"""
+    n_pass, osc = (1, 2.0) if form == "B" else (2, 1.0)
+    A = O.arch(H=H, act=act, n_pass=n_pass, out_scale=osc)
+    rng = np.random.default_rng(11 + H)
     off, sz = O.tensor_layout(A)
     theta = np.zeros(O.param_count(A))
-    fan = [2, 2, 64, 64, 64, 64, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    fan = [2, 2, H, H, H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
     for o, s, fi in zip(off, sz, fan):
         theta[o:o + s] = rng.uniform(-1, 1, s) / np.sqrt(fi)
-    n = 3000
+    n = 3001                                           # ragged: exercises the padded last tile
     x, y, z = rng.uniform(-18, 18, (3, n))
     R = rng.uniform(0.2, 3, n)
     mask = ((np.sqrt((x - R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8)
             + 2 * (np.sqrt((x + R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8))
-    _mfma_case(theta, x, y, z, R, mask, 1, "B", A, O.ham_B())
+    _mfma_case(theta, x, y, z, R, mask, act, form, A, O.ham_B() if form == "B" else O.ham_A(), H=H)
 
 
 def test_fine_tune_mode_trains_only_the_E_net(golden_dir):

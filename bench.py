@@ -48,6 +48,14 @@ ARCHS["wide128"] = dict(H=128, L=2, HE=32, HG=10, act=1, n_pass=2, out_scale=1.0
                         act_name="tanh", peak=2500.0, dtype="bf16",
                         label="2x128 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "
                               "accumulate, seeded random init")
+ARCHS["wide4x64"] = dict(H=64, L=4, HE=32, HG=10, act=1, n_pass=2, out_scale=1.0, precision="bf16",
+                         act_name="tanh", peak=2500.0, dtype="bf16",
+                         label="4x64 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "
+                               "accumulate, seeded random init")
+ARCHS["wide4x128"] = dict(H=128, L=4, HE=32, HG=10, act=1, n_pass=2, out_scale=1.0, precision="bf16",
+                          act_name="tanh", peak=2500.0, dtype="bf16",
+                          label="4x128 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "
+                                "accumulate, seeded random init")
 DEFAULT_ARCH = "wide64"
 
 

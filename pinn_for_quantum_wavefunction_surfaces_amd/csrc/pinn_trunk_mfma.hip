@@ -585,7 +585,11 @@ struct M2Cfg {
     static constexpr int HT = H / 16, KC = H / 32, NW = L - 1;
     static constexpr int GROUPS = WAVES / SPLIT;
     static_assert(H / SPLIT == 32, "each wave owns 32 neurons");
-    static constexpr int WPK = NW * 2 * H * H;                    // bf16 elements
+    static constexpr int WPK_ALL = NW * 2 * H * H;                // bf16 elements
+    // packed weights are staged in LDS when they fit beside the exchange buffers; otherwise
+    // (4x128: 192 KB) the A fragments are read from global memory, where they stay L2-resident
+    static constexpr bool WLDS = (size_t)WPK_ALL * 2 <= 64 * 1024;
+    static constexpr int WPK = WLDS ? WPK_ALL : 0;
     static constexpr int NSMALL = 3 * H + NW * H + H + 4;         // floats
     static constexpr int EB = KC * 5 * 64 * 16;                   // bytes of one exchange buffer
     static constexpr int SBYTES = SPLIT * 16 * 2 * 4;             // per-group partial (Sv, Sl)
@@ -625,9 +629,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
     float* SB = reinterpret_cast<float*>(YB + C::EB);   // [SPLIT][16][2]
 
     {
-        const uint4* src = reinterpret_cast<const uint4*>(wpk_g);
-        uint4* dst = reinterpret_cast<uint4*>(wpk);
-        for (int k = threadIdx.x; k < C::WPK / 8; k += NT) dst[k] = src[k];
+        if (C::WLDS) {
+            const uint4* src = reinterpret_cast<const uint4*>(wpk_g);
+            uint4* dst = reinterpret_cast<uint4*>(wpk);
+            for (int k = threadIdx.x; k < C::WPK / 8; k += NT) dst[k] = src[k];
+        }
         for (int k = threadIdx.x; k < 2 * H; k += NT) sW0[k] = theta[Lay::W(0) + k];
         for (int k = threadIdx.x; k < H; k += NT) {
             sb0[k] = theta[Lay::b(0) + k];
@@ -639,6 +645,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
         for (int k = threadIdx.x; k < C::ZBYTES / 4; k += NT) reinterpret_cast<unsigned*>(zero)[k] = 0u;
     }
     __syncthreads();
+    const __bf16* wsrc = C::WLDS ? wpk : wpk_g;   // one provenance per instantiation
 
     // ---- persistent gradient state (own 32 neurons = row tiles 2*part, 2*part+1)
     f32x4 wacc[NW][2][HT];
@@ -735,7 +742,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
             float Sv = 0.f, Sl = 0.f;
 #pragma unroll
             for (int l = 1; l < L; l++) {
-                const __bf16* wf = wpk + (size_t)((l - 1) * 2 + 0) * H * H;
+                const __bf16* wf = wsrc + (size_t)((l - 1) * 2 + 0) * H * H;
                 const unsigned char* xin = XB + (size_t)(l - 1) * C::EB;
                 f32x4 a[2][5];
 #pragma unroll
@@ -904,7 +911,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                     }
                 }
                 // ---- adjoint of layer l's input for the own neurons, then layer l-1's activation adjoint
-                const __bf16* wb = wpk + (size_t)((l - 1) * 2 + 1) * H * H;
+                const __bf16* wb = wsrc + (size_t)((l - 1) * 2 + 1) * H * H;
                 f32x4 ob[2][5];
 #pragma unroll
                 for (int tt = 0; tt < 2; tt++)
@@ -986,8 +993,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
     // =========================== block reduction ===========================
     __syncthreads();
     constexpr int PT = Lay::size;
-    float* gimg = reinterpret_cast<float*>(lds_raw);
-    float* sc = gimg + PT;
+    float* out = A.partial + (size_t)blockIdx.x * A.stride;
     const float s0 = row16_sum(xg_sum(acc_pde)), s1r = row16_sum(xg_sum(acc_bc1)),
                 s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
     if (MODE == MODE_BWD) {
@@ -1001,6 +1007,52 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                 w0acc[tt][1][r] = row16_sum(w0acc[tt][1][r]);
                 woacc[tt][r] = row16_sum(woacc[tt][r]);
             }
+    }
+    if (C::GROUPS == 1) {
+        // one group per block: every wave owns distinct gradient rows -> write them straight to
+        // the block's partial row (the LDS image of a 4x128 trunk would not fit anyway)
+        float* sc = reinterpret_cast<float*>(lds_raw);
+        if (threadIdx.x < 4) sc[threadIdx.x] = 0.f;
+        __syncthreads();
+        if (MODE == MODE_BWD) {
+#pragma unroll
+            for (int l = 1; l < L; l++)
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int it = 0; it < HT; it++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int nj = q_neuron(16 * (2 * part + tt) + 4 * g + r), ni = q_neuron(16 * it + c);
+                            out[Lay::W(l) + nj * H + ni] = wacc[l - 1][tt][it][r];
+                        }
+            if (c == 0) {
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int nj = 32 * part + 16 * tt + 4 * g + r;
+#pragma unroll
+                        for (int l = 0; l < L; l++) out[Lay::b(l) + nj] = bacc[l][tt][r];
+                        out[Lay::W(0) + 2 * nj] = w0acc[tt][0][r];
+                        out[Lay::W(0) + 2 * nj + 1] = w0acc[tt][1][r];
+                        out[Lay::Wout + nj] = woacc[tt][r];
+                    }
+            }
+        } else {
+            for (int k = threadIdx.x; k < PT; k += NT) out[k] = 0.0f;
+        }
+        for (int w = 0; w < WAVES; w++) {   // per-point sums live in part 0 only; fixed order anyway
+            if (wave == w && lane == 0) { sc[0] += s0; sc[1] += s1r; sc[2] += s2r; sc[3] += s3r; }
+            __syncthreads();
+        }
+        if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
+        if (threadIdx.x == 3 && MODE == MODE_BWD) out[Lay::bout] = sc[3];
+        return;
+    }
+    float* gimg = reinterpret_cast<float*>(lds_raw);
+    float* sc = gimg + PT;
+    if (MODE == MODE_BWD) {
         // zero the image once (each wave only touches its own rows; several groups add into them)
         for (int k = threadIdx.x; k < PT + 4; k += NT) gimg[k] = 0.f;
     } else {
@@ -1039,7 +1091,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
         }
         __syncthreads();
     }
-    float* out = A.partial + (size_t)blockIdx.x * A.stride;
     if (MODE == MODE_BWD) {
         for (int k = threadIdx.x; k < PT; k += NT) out[k] = k == Lay::bout ? sc[3] : gimg[k];
     } else {
@@ -1059,7 +1110,7 @@ hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int gr
     if (e != hipSuccess) return e;
     auto kern = k_trunk_mfma2<H, L, ACT, NPASS, MODE, SPLIT, WAVES>;
     size_t lds = C::LDS_BYTES;
-    const size_t need = (size_t)(TrunkLayout<H, L>::size + 16) * 4;
+    const size_t need = C::GROUPS == 1 ? 64 : (size_t)(TrunkLayout<H, L>::size + 16) * 4;
     if (lds < need) lds = need;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1121,7 +1172,7 @@ bool launch_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, co
 
 }  // namespace
 
-bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && L == 2; }
+bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
 
 // H = 64 can run either generation.  Measured (1M points, 2x64 tanh, symmetric): point-split
 // 0.90 ms, neuron-split 1.02 ms, so the first generation is the default there; PINN_MFMA_GEN=2
@@ -1150,5 +1201,7 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, const float* 
         return launch2_HL<64, 2, 2, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
     }
     if (H == 128 && L == 2) return launch2_HL<128, 2, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+    if (H == 64 && L == 4) return launch2_HL<64, 4, 2, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+    if (H == 128 && L == 4) return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
     return false;
 }

@@ -303,9 +303,9 @@ def test_training_reduces_the_loss_and_full_size_properties():
 # reference network); the tolerances below are this path's own, relative to max-norms:
 #   psi 1e-2, E 1e-5 (E-net stays fp32), lap 1e-2, residual 2e-2, loss 3e-2, gradient 3e-2
 # (observed on these cases: psi 1e-4..4e-3, residual 2e-4..5e-3, gradient 2e-3..8e-3).
-def _mfma_case(theta, x, y, z, R, mask, act, form, A_or, Hm_or, H=64):
+def _mfma_case(theta, x, y, z, R, mask, act, form, A_or, Hm_or, H=64, L=2):
     f = pkg.model.FORMULATION_A if form == "A" else pkg.model.FORMULATION_B
-    arch = capi.Arch(H, 2, 32, 10, act, f["n_pass"], f["out_scale"], capi.PINN_PREC_BF16)
+    arch = capi.Arch(H, L, 32, 10, act, f["n_pass"], f["out_scale"], capi.PINN_PREC_BF16)
     h = capi.Handle(arch, 0, 4096)
     fw = O.forward(A_or, Hm_or, theta, x, y, z, R)
     ref = O.loss_grad(A_or, Hm_or, theta, x, y, z, R, mask)
@@ -316,7 +316,7 @@ def _mfma_case(theta, x, y, z, R, mask, act, form, A_or, Hm_or, H=64):
                 res=rel(res, fw["res"]), loss=abs(out[P:].sum() / ref["Ltot"] - 1),
                 grad=rel(out[:P], ref["grad"]))
     off, sz = capi.tensor_layout(arch)
-    names = ["W0", "b0", "W1", "b1", "wout", "bout"]
+    names = [k for l in range(L) for k in ("W%d" % l, "b%d" % l)] + ["wout", "bout"]
     for t, nm in enumerate(names):
         r = ref["grad"][off[t]:off[t] + sz[t]]
         errs["g_" + nm] = np.max(np.abs(out[off[t]:off[t] + sz[t]] - r)) / max(np.max(np.abs(r)), 1e-30)
@@ -337,24 +337,25 @@ def test_mfma_bf16_wide_trunk_matches_reference(golden_dir):
                O.arch(H=64), O.ham_A())
 
 
-@pytest.mark.parametrize("H,form,act", [(64, "B", 1), (128, "A", 0), (128, "B", 1)])
-def test_mfma_bf16_matches_oracle(H, form, act):
-    """wide shapes without a reference vector ('2x64 tanh' in train.py's single-pass form, and
-    2x128 in both formulations on the 4-wave neuron-split kernel): oracle only"""
+@pytest.mark.parametrize("H,L,form,act", [(64, 2, "B", 1), (128, 2, "A", 0), (128, 2, "B", 1),
+                                           (64, 4, "A", 1), (128, 4, "A", 1), (128, 4, "B", 0)])
+def test_mfma_bf16_matches_oracle(H, L, form, act):
+    """wide shapes without a reference vector ('2x64 tanh' in train.py's single-pass form; 2x128,
+    4x64 and BASELINE's 4x128 on the neuron-split kernel): oracle only"""
     n_pass, osc = (1, 2.0) if form == "B" else (2, 1.0)
-    A = O.arch(H=H, act=act, n_pass=n_pass, out_scale=osc)
-    rng = np.random.default_rng(11 + H)
+    A = O.arch(H=H, L=L, act=act, n_pass=n_pass, out_scale=osc)
+    rng = np.random.default_rng(11 + H + L)
     off, sz = O.tensor_layout(A)
     theta = np.zeros(O.param_count(A))
-    fan = [2, 2, H, H, H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    fan = [2, 2] + [H, H] * (L - 1) + [H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
     for o, s, fi in zip(off, sz, fan):
         theta[o:o + s] = rng.uniform(-1, 1, s) / np.sqrt(fi)
-    n = 3001                                           # ragged: exercises the padded last tile
+    n = 3001 if L == 2 else 1001                       # ragged: exercises the padded last tile
     x, y, z = rng.uniform(-18, 18, (3, n))
     R = rng.uniform(0.2, 3, n)
     mask = ((np.sqrt((x - R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8)
             + 2 * (np.sqrt((x + R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8))
-    _mfma_case(theta, x, y, z, R, mask, act, form, A, O.ham_B() if form == "B" else O.ham_A(), H=H)
+    _mfma_case(theta, x, y, z, R, mask, act, form, A, O.ham_B() if form == "B" else O.ham_A(), H=H, L=L)
 
 
 def test_fine_tune_mode_trains_only_the_E_net(golden_dir):

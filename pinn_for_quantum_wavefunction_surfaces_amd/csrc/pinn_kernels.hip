@@ -98,6 +98,31 @@ __device__ __forceinline__ void mma(f32x4& acc, const Frag& a, const Frag& b)
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[t], b.v[t], acc, 0, 0, 0);
 }
 
+// One MFMA step of several independent accumulator chains at a time: a 16x16x4 f32 MFMA can issue
+// every 32 cycles but its result is only available after 40, so back-to-back steps of ONE chain
+// stall the (in-order) wave; stepping all tiles of a call together keeps the pipe busy.
+template <int NA, int NB>
+__device__ __forceinline__ void mma_grid(f32x4 (&acc)[NA][NB], const Frag (&a)[NA], const Frag (&b)[NB])
+{
+#pragma unroll
+    for (int t = 0; t < 16; t++)
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].v[t], b[j].v[t], acc[i][j], 0, 0, 0);
+}
+
+template <int NA>
+__device__ __forceinline__ void mma_col(f32x4 (&acc)[NA], const Frag (&a)[NA], const Frag& b)
+{
+#pragma unroll
+    for (int t = 0; t < 16; t++)
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].v[t], b.v[t], acc[i], 0, 0, 0);
+}
+
 // tile element (row = 4*(lane>>4) + r, col = lane&15) lives in acc[r]
 __device__ __forceinline__ void tile_store(const f32x4& acc, float* dst, int row_stride,
                                            int col_stride, int nrow, int ncol, int lane, bool add)
@@ -198,16 +223,12 @@ struct TrunkSink {
         stage_rows<H>(U, 0, ab, lane);
         stage_rows<H>(V, 0, oin, lane);
         wave_lds_sync();
-        Frag fa[HT];
+        Frag fa[HT], fb[HT];
 #pragma unroll
         for (int a = 0; a < HT; a++) load_frag(U, a, lane, fa[a]);
 #pragma unroll
-        for (int b = 0; b < HT; b++) {
-            Frag fb;
-            load_frag(V, b, lane, fb);
-#pragma unroll
-            for (int a = 0; a < HT; a++) mma(tW[l - 1][a][b], fa[a], fb);
-        }
+        for (int b = 0; b < HT; b++) load_frag(V, b, lane, fb[b]);
+        mma_grid<HT, HT>(tW[l - 1], fa, fb);
         if (s == 0) {
 #pragma unroll
             for (int j = 0; j < H; j++) accB[l][j] += ab[j];
@@ -409,7 +430,7 @@ struct RnetSink {
     float* U;
     float* V;
     int lane;
-    f32x4 tE2[ET][ET], tbE2[ET], tE3[ET], tE1[ET], tG2, tG1;
+    f32x4 tE2[ET][ET], tbE2[ET], tE3[ET], tE1[ET], tG2, tG1[1];
     float bE3, bG2;
 
     __device__ __forceinline__ void zero()
@@ -421,21 +442,18 @@ struct RnetSink {
 #pragma unroll
             for (int b = 0; b < ET; b++) tE2[a][b] = z;
         }
-        tG2 = z; tG1 = z;
+        tG2 = z; tG1[0] = z;
         bE3 = 0.f; bG2 = 0.f;
     }
     __device__ __forceinline__ void e3(const float (&t3)[HE], float Eb)
     {
         stage_rows<HE>(U, 0, t3, lane);
         wave_lds_sync();
-        Frag one;
+        Frag one, fa[ET];
         const_frag(0, 1.0f, lane, one);
 #pragma unroll
-        for (int a = 0; a < ET; a++) {
-            Frag fa;
-            load_frag(U, a, lane, fa);
-            mma(tE3[a], fa, one);
-        }
+        for (int a = 0; a < ET; a++) load_frag(U, a, lane, fa[a]);
+        mma_col<ET>(tE3, fa, one);
         bE3 += Eb;
     }
     __device__ __forceinline__ void e2(const float (&a2)[HE], const float (&h1)[HE])
@@ -443,40 +461,31 @@ struct RnetSink {
         stage_rows<HE>(U, 0, a2, lane);
         stage_rows<HE>(V, 0, h1, lane);
         wave_lds_sync();
-        Frag fa[ET], one;
+        Frag fa[ET], fb[ET], one;
         const_frag(0, 1.0f, lane, one);
 #pragma unroll
-        for (int a = 0; a < ET; a++) {
-            load_frag(U, a, lane, fa[a]);
-            mma(tbE2[a], fa[a], one);
-        }
+        for (int a = 0; a < ET; a++) load_frag(U, a, lane, fa[a]);
 #pragma unroll
-        for (int b = 0; b < ET; b++) {
-            Frag fb;
-            load_frag(V, b, lane, fb);
-#pragma unroll
-            for (int a = 0; a < ET; a++) mma(tE2[a][b], fa[a], fb);
-        }
+        for (int b = 0; b < ET; b++) load_frag(V, b, lane, fb[b]);
+        mma_grid<ET, ET>(tE2, fa, fb);
+        mma_col<ET>(tbE2, fa, one);
     }
     // cols 0,1 of the tile: sum a*R, sum a
     template <int N>
-    __device__ __forceinline__ void times_R_and_1(f32x4* tiles, const float (&a)[N], float Rv)
+    __device__ __forceinline__ void times_R_and_1(f32x4 (&tiles)[(N + 15) / 16], const float (&a)[N], float Rv)
     {
         stage_rows<N>(U, 0, a, lane);
         stage_row(V, 0, Rv, lane);
         stage_row(V, 1, 1.0f, lane);
         wave_lds_sync();
-        Frag fb;
+        Frag fb, fa[(N + 15) / 16];
         load_frag(V, 0, lane, fb);
 #pragma unroll
-        for (int t = 0; t < (N + 15) / 16; t++) {
-            Frag fa;
-            load_frag(U, t, lane, fa);
-            mma(tiles[t], fa, fb);
-        }
+        for (int t = 0; t < (N + 15) / 16; t++) load_frag(U, t, lane, fa[t]);
+        mma_col<(N + 15) / 16>(tiles, fa, fb);
     }
     __device__ __forceinline__ void e1(const float (&a1)[HE], float Rv) { times_R_and_1<HE>(tE1, a1, Rv); }
-    __device__ __forceinline__ void g1(const float (&ag)[HG], float Rv) { times_R_and_1<HG>(&tG1, ag, Rv); }
+    __device__ __forceinline__ void g1(const float (&ag)[HG], float Rv) { times_R_and_1<HG>(tG1, ag, Rv); }
     __device__ __forceinline__ void g2(const float (&tg)[HG], float gb)
     {
         stage_rows<HG>(U, 0, tg, lane);
@@ -504,7 +513,7 @@ struct RnetSink {
             tile_store(tE1[a], g + Lo.WE1() + 16 * a, 1, HE, nr, 2, lane, add);
         }
         tile_store(tG2, g + Lo.WG2(), 1, 0, HG, 1, lane, add);
-        tile_store(tG1, g + Lo.WG1(), 1, HG, HG, 2, lane, add);
+        tile_store(tG1[0], g + Lo.WG1(), 1, HG, HG, 2, lane, add);
     }
 };
 

@@ -146,17 +146,55 @@ PINN_HD void orbital(T dx, T dy, T dz, T st[5], T& rinv)
 }
 
 // -------------------------------------------------------------------- trunk
-// State of one symmetric pass for one point.  o[l] = post-activation streams
-// of layers 0..L-2 (inputs of the next layer, also the V operand of the weight
-// gradient); a[l-1] = (h, a_x, a_y, a_z, a_lap) of layers 1..L-1 (what the
-// activation adjoint needs).  Layer 0's pre-activations are recomputed in the
-// reverse pass (K = 2), which keeps the live set at 10*H floats for L = 2.
+// pair versions of the activation helpers: the transcendental unit works per half, everything
+// else is packed arithmetic
+template <int ACT, class T>
+PINN_HD void act012_2(typename V2<T>::type a, typename V2<T>::type& s, typename V2<T>::type& s1,
+                      typename V2<T>::type& s2)
+{
+    using V = typename V2<T>::type;
+    if (ACT == ACT_SIGMOID) {
+        const V d = make2<T>(T(1) + p_exp(-a[0]), T(1) + p_exp(-a[1]));
+        s = make2<T>(p_rcp(d[0]), p_rcp(d[1]));
+        s1 = s - s * s;
+        s2 = s1 - T(2) * s * s1;
+    } else {
+        const V d = make2<T>(T(1) + p_exp(T(-2) * a[0]), T(1) + p_exp(T(-2) * a[1]));
+        s = T(2) * make2<T>(p_rcp(d[0]), p_rcp(d[1])) - T(1);
+        s1 = T(1) - s * s;
+        s2 = T(-2) * s * s1;
+    }
+}
+
+template <int ACT, class T>
+PINN_HD void act123_2(typename V2<T>::type s, typename V2<T>::type& s1, typename V2<T>::type& s2,
+                      typename V2<T>::type& s3)
+{
+    if (ACT == ACT_SIGMOID) {
+        s1 = s - s * s;
+        s2 = s1 - T(2) * s * s1;
+        s3 = s1 - T(6) * s1 * s1;
+    } else {
+        s1 = T(1) - s * s;
+        s2 = T(-2) * s * s1;
+        s3 = s1 * (T(4) - T(6) * s1);
+    }
+}
+
+// State of one symmetric pass for one point, held as neuron PAIRS.  o[l] = post-activation
+// streams of layers 0..L-2 (inputs of the next layer, also the V operand of the weight
+// gradient); a[l-1] = (h, a_x, a_y, a_z, a_lap) of layers 1..L-1 (what the activation adjoint
+// needs).  Layer 0's pre-activations are recomputed in the reverse pass (K = 2), which keeps
+// the live set at 10*H floats for L = 2.
 template <int H, int L, int ACT, class T>
 struct TrunkPass {
     static_assert(L >= 2, "trunk needs at least two hidden layers");
+    static_assert(H % 2 == 0, "trunk width must be even");
     using Lay = TrunkLayout<H, L>;
-    T o[L - 1][5][H];
-    T a[L - 1][5][H];
+    using V = typename V2<T>::type;
+    static constexpr int HP = H / 2;
+    V o[L - 1][5][HP];
+    V a[L - 1][5][HP];
 
     // Forward.  Adds sum_j wout[j]*B_v[j] to Sv and sum_j wout[j]*B_lap[j] to Sl
     // (Lin_out, poc/main.py:261; train.py:47).
@@ -164,9 +202,6 @@ struct TrunkPass {
     PINN_HD void forward(const W* __restrict__ th, const W* __restrict__ thT, const T (&in)[2][5],
                          T& Sv, T& Sl)
     {
-        using V = typename V2<T>::type;
-        constexpr int HP = H / 2;
-        static_assert(H % 2 == 0, "trunk width must be even");
         {   // ---- layer 0 (K = 2): two rank-1 updates on neuron pairs
             V A[5][HP];
             {
@@ -190,16 +225,14 @@ struct TrunkPass {
                 PINN_ROW_FENCE();
             }
 #pragma unroll
-            for (int j = 0; j < H; j++) {
-                const T a0 = A[0][j >> 1][j & 1], ax = A[1][j >> 1][j & 1], ay = A[2][j >> 1][j & 1],
-                        az = A[3][j >> 1][j & 1], al = A[4][j >> 1][j & 1];
-                T s, s1, s2;
-                act012<ACT>(a0, s, s1, s2);
-                o[0][0][j] = s;
-                o[0][1][j] = s1 * ax;
-                o[0][2][j] = s1 * ay;
-                o[0][3][j] = s1 * az;
-                o[0][4][j] = s1 * al + s2 * (ax * ax + ay * ay + az * az);
+            for (int p = 0; p < HP; p++) {
+                V s, s1, s2;
+                act012_2<ACT, T>(A[0][p], s, s1, s2);
+                o[0][0][p] = s;
+                o[0][1][p] = s1 * A[1][p];
+                o[0][2][p] = s1 * A[2][p];
+                o[0][3][p] = s1 * A[3][p];
+                o[0][4][p] = s1 * A[4][p] + s2 * (A[1][p] * A[1][p] + A[2][p] * A[2][p] + A[3][p] * A[3][p]);
             }
             PINN_ROW_FENCE();
         }
@@ -231,7 +264,7 @@ struct TrunkPass {
                 PINN_ROW_FENCE();
 #pragma unroll
                 for (int s = 0; s < 5; s++) {
-                    const V xs = splat2<T>(o[l - 1][s][i]);
+                    const V xs = splat2<T>(o[l - 1][s][i >> 1][i & 1]);
 #pragma unroll
                     for (int p = 0; p < HP; p++) {
                         A[s][p] += wc[p] * xs;
@@ -242,34 +275,38 @@ struct TrunkPass {
 #pragma unroll
                 for (int p = 0; p < HP; p++) wc[p] = wn[p];
             }
-            T wo_[H];
+            V wo2[HP];
             if (l == L - 1) {
 #pragma unroll
-                for (int j = 0; j < H; j++) wo_[j] = T(th[Lay::Wout + j]);
+                for (int p = 0; p < HP; p++)
+                    wo2[p] = make2<T>(T(th[Lay::Wout + 2 * p]), T(th[Lay::Wout + 2 * p + 1]));
                 PINN_ROW_FENCE();
             }
+            V accv = splat2<T>(T(0)), accl = splat2<T>(T(0));
 #pragma unroll
-            for (int j = 0; j < H; j++) {
-                const T c0 = A[0][j >> 1][j & 1], cx = A[1][j >> 1][j & 1], cy = A[2][j >> 1][j & 1],
-                        cz = A[3][j >> 1][j & 1], cl = A[4][j >> 1][j & 1];
-                T s, s1, s2;
-                act012<ACT>(c0, s, s1, s2);
-                a[l - 1][0][j] = s;
-                a[l - 1][1][j] = cx;
-                a[l - 1][2][j] = cy;
-                a[l - 1][3][j] = cz;
-                a[l - 1][4][j] = cl;
-                T ol = s1 * cl + s2 * (cx * cx + cy * cy + cz * cz);
+            for (int p = 0; p < HP; p++) {
+                V s, s1, s2;
+                act012_2<ACT, T>(A[0][p], s, s1, s2);
+                const V ol = s1 * A[4][p] + s2 * (A[1][p] * A[1][p] + A[2][p] * A[2][p] + A[3][p] * A[3][p]);
+                a[l - 1][0][p] = s;
+                a[l - 1][1][p] = A[1][p];
+                a[l - 1][2][p] = A[2][p];
+                a[l - 1][3][p] = A[3][p];
+                a[l - 1][4][p] = A[4][p];
                 if (l < L - 1) {
-                    o[l][0][j] = s;
-                    o[l][1][j] = s1 * cx;
-                    o[l][2][j] = s1 * cy;
-                    o[l][3][j] = s1 * cz;
-                    o[l][4][j] = ol;
+                    o[l][0][p] = s;
+                    o[l][1][p] = s1 * A[1][p];
+                    o[l][2][p] = s1 * A[2][p];
+                    o[l][3][p] = s1 * A[3][p];
+                    o[l][4][p] = ol;
                 } else {
-                    Sv += wo_[j] * s;
-                    Sl += wo_[j] * ol;
+                    accv += wo2[p] * s;
+                    accl += wo2[p] * ol;
                 }
+            }
+            if (l == L - 1) {
+                Sv += accv[0] + accv[1];
+                Sl += accl[0] + accl[1];
             }
             PINN_ROW_FENCE();
         }
@@ -283,32 +320,33 @@ struct TrunkPass {
     PINN_HD void backward(const W* __restrict__ th, const W* __restrict__ thT, const T (&in)[2][5],
                           T cv, T cl, Sink& sink)
     {
-        using V = typename V2<T>::type;
-        constexpr int HP = H / 2;
-        T ob[5][H];  // adjoint of the current layer's post-activation streams
-        T ab[5][H];  // adjoint of its pre-activation streams
+        V ob[5][HP];  // adjoint of the current layer's post-activation streams (pairs)
+        V ab[5][HP];  // adjoint of its pre-activation streams
         // ---- last hidden layer: only the value and Laplacian streams feed Lin_out
         {
-            T t[H], wo_[H];
+            V wo2[HP];
 #pragma unroll
-            for (int j = 0; j < H; j++) wo_[j] = T(th[Lay::Wout + j]);
+            for (int p = 0; p < HP; p++)
+                wo2[p] = make2<T>(T(th[Lay::Wout + 2 * p]), T(th[Lay::Wout + 2 * p + 1]));
             PINN_ROW_FENCE();
+            T t[H];
 #pragma unroll
-            for (int j = 0; j < H; j++) {
-                T s = a[L - 2][0][j], ax = a[L - 2][1][j], ay = a[L - 2][2][j],
-                  az = a[L - 2][3][j], al = a[L - 2][4][j];
-                T s1, s2, s3;
-                act123<ACT>(s, s1, s2, s3);
-                T q = ax * ax + ay * ay + az * az;
-                t[j] = cv * s + cl * (s1 * al + s2 * q);  // d/d wout[j]
-                T wo = wo_[j];
-                T o0 = cv * wo, ol = cl * wo;
-                T u = T(2) * s2 * ol;
-                ab[4][j] = s1 * ol;
-                ab[1][j] = u * ax;
-                ab[2][j] = u * ay;
-                ab[3][j] = u * az;
-                ab[0][j] = s1 * o0 + (s2 * al + s3 * q) * ol;
+            for (int p = 0; p < HP; p++) {
+                const V s = a[L - 2][0][p], ax = a[L - 2][1][p], ay = a[L - 2][2][p], az = a[L - 2][3][p],
+                        al = a[L - 2][4][p];
+                V s1, s2, s3;
+                act123_2<ACT, T>(s, s1, s2, s3);
+                const V q = ax * ax + ay * ay + az * az;
+                const V tt = cv * s + cl * (s1 * al + s2 * q);  // d/d wout
+                t[2 * p] = tt[0];
+                t[2 * p + 1] = tt[1];
+                const V o0 = cv * wo2[p], ol = cl * wo2[p];
+                const V u = T(2) * s2 * ol;
+                ab[4][p] = s1 * ol;
+                ab[1][p] = u * ax;
+                ab[2][p] = u * ay;
+                ab[3][p] = u * az;
+                ab[0][p] = s1 * o0 + (s2 * al + s3 * q) * ol;
             }
             PINN_ROW_FENCE();
             sink.out_weight(t);
@@ -317,33 +355,35 @@ struct TrunkPass {
         for (int l = L - 1; l >= 1; l--) {
             if (l < L - 1) {  // middle layer: full five-stream adjoint
 #pragma unroll
-                for (int j = 0; j < H; j++) {
-                    T s = a[l - 1][0][j], ax = a[l - 1][1][j], ay = a[l - 1][2][j],
-                      az = a[l - 1][3][j], al = a[l - 1][4][j];
-                    T s1, s2, s3;
-                    act123<ACT>(s, s1, s2, s3);
-                    T q = ax * ax + ay * ay + az * az;
-                    T o0 = ob[0][j], ox = ob[1][j], oy = ob[2][j], oz = ob[3][j], ol = ob[4][j];
-                    T u = T(2) * s2 * ol;
-                    ab[4][j] = s1 * ol;
-                    ab[1][j] = s1 * ox + u * ax;
-                    ab[2][j] = s1 * oy + u * ay;
-                    ab[3][j] = s1 * oz + u * az;
-                    ab[0][j] = s1 * o0 + s2 * (ax * ox + ay * oy + az * oz) + (s2 * al + s3 * q) * ol;
+                for (int p = 0; p < HP; p++) {
+                    const V s = a[l - 1][0][p], ax = a[l - 1][1][p], ay = a[l - 1][2][p],
+                            az = a[l - 1][3][p], al = a[l - 1][4][p];
+                    V s1, s2, s3;
+                    act123_2<ACT, T>(s, s1, s2, s3);
+                    const V q = ax * ax + ay * ay + az * az;
+                    const V u = T(2) * s2 * ob[4][p];
+                    ab[4][p] = s1 * ob[4][p];
+                    ab[1][p] = s1 * ob[1][p] + u * ax;
+                    ab[2][p] = s1 * ob[2][p] + u * ay;
+                    ab[3][p] = s1 * ob[3][p] + u * az;
+                    ab[0][p] = s1 * ob[0][p] + s2 * (ax * ob[1][p] + ay * ob[2][p] + az * ob[3][p]) +
+                               (s2 * al + s3 * q) * ob[4][p];
                 }
             }
 #pragma unroll
             for (int s = 0; s < 5; s++) {
                 // W_l-bar += ab_s (x) o_{l-1,s}; the s == 0 call also carries b_l-bar += ab_0
-                sink.weight(l, s, ab[s], o[l - 1][s]);
+                T us[H], vs[H];
+#pragma unroll
+                for (int j = 0; j < H; j++) { us[j] = ab[s][j >> 1][j & 1]; vs[j] = o[l - 1][s][j >> 1][j & 1]; }
+                sink.weight(l, s, us, vs);
             }
             // adjoint of the layer input: ob_s = W_l^T ab_s as rank-1 updates on input-neuron
             // pairs: row j of W_l (contiguous, double-buffered scalar loads) x ab_s[j]
-            V ob2[5][HP];
 #pragma unroll
             for (int s = 0; s < 5; s++)
 #pragma unroll
-                for (int p = 0; p < HP; p++) ob2[s][p] = splat2<T>(T(0));
+                for (int p = 0; p < HP; p++) ob[s][p] = splat2<T>(T(0));
             V wc[HP], wn[HP];
 #pragma unroll
             for (int p = 0; p < HP; p++)
@@ -360,47 +400,53 @@ struct TrunkPass {
                 PINN_ROW_FENCE();
 #pragma unroll
                 for (int s = 0; s < 5; s++) {
-                    const V xs = splat2<T>(ab[s][j]);
+                    const V xs = splat2<T>(ab[s][j >> 1][j & 1]);
 #pragma unroll
                     for (int p = 0; p < HP; p++) {
-                        ob2[s][p] += wc[p] * xs;
-                        PINN_PIN(ob2[s][p]);
+                        ob[s][p] += wc[p] * xs;
+                        PINN_PIN(ob[s][p]);
                     }
                 }
                 PINN_ROW_FENCE();
 #pragma unroll
                 for (int p = 0; p < HP; p++) wc[p] = wn[p];
             }
-#pragma unroll
-            for (int s = 0; s < 5; s++)
-#pragma unroll
-                for (int i = 0; i < H; i++) ob[s][i] = ob2[s][i >> 1][i & 1];
         }
         // ---- layer 0: recompute its pre-activation derivative streams (K = 2)
-        T w0_[2 * H];
+        {
+            V w0[HP], w1[HP];
 #pragma unroll
-        for (int k = 0; k < 2 * H; k++) w0_[k] = T(thT[Lay::W(0) + k]);  // [2][H]
-        PINN_ROW_FENCE();
+            for (int p = 0; p < HP; p++) {
+                w0[p] = make2<T>(T(thT[Lay::W(0) + 2 * p]), T(thT[Lay::W(0) + 2 * p + 1]));
+                w1[p] = make2<T>(T(thT[Lay::W(0) + H + 2 * p]), T(thT[Lay::W(0) + H + 2 * p + 1]));
+            }
+            PINN_ROW_FENCE();
 #pragma unroll
-        for (int j = 0; j < H; j++) {
-            T w0 = w0_[j], w1 = w0_[H + j];
-            T ax = w0 * in[0][1] + w1 * in[1][1];
-            T ay = w0 * in[0][2] + w1 * in[1][2];
-            T az = w0 * in[0][3] + w1 * in[1][3];
-            T al = w0 * in[0][4] + w1 * in[1][4];
-            T s = o[0][0][j], s1, s2, s3;
-            act123<ACT>(s, s1, s2, s3);
-            T q = ax * ax + ay * ay + az * az;
-            T o0 = ob[0][j], ox = ob[1][j], oy = ob[2][j], oz = ob[3][j], ol = ob[4][j];
-            T u = T(2) * s2 * ol;
-            ab[4][j] = s1 * ol;
-            ab[1][j] = s1 * ox + u * ax;
-            ab[2][j] = s1 * oy + u * ay;
-            ab[3][j] = s1 * oz + u * az;
-            ab[0][j] = s1 * o0 + s2 * (ax * ox + ay * oy + az * oz) + (s2 * al + s3 * q) * ol;
+            for (int p = 0; p < HP; p++) {
+                const V ax = w0[p] * in[0][1] + w1[p] * in[1][1];
+                const V ay = w0[p] * in[0][2] + w1[p] * in[1][2];
+                const V az = w0[p] * in[0][3] + w1[p] * in[1][3];
+                const V al = w0[p] * in[0][4] + w1[p] * in[1][4];
+                V s1, s2, s3;
+                act123_2<ACT, T>(o[0][0][p], s1, s2, s3);
+                const V q = ax * ax + ay * ay + az * az;
+                const V u = T(2) * s2 * ob[4][p];
+                ab[4][p] = s1 * ob[4][p];
+                ab[1][p] = s1 * ob[1][p] + u * ax;
+                ab[2][p] = s1 * ob[2][p] + u * ay;
+                ab[3][p] = s1 * ob[3][p] + u * az;
+                ab[0][p] = s1 * ob[0][p] + s2 * (ax * ob[1][p] + ay * ob[2][p] + az * ob[3][p]) +
+                           (s2 * al + s3 * q) * ob[4][p];
+            }
+            PINN_ROW_FENCE();
         }
 #pragma unroll
-        for (int s = 0; s < 5; s++) sink.weight0(s, ab[s], in[0][s], in[1][s]);  // s == 0: + bias
+        for (int s = 0; s < 5; s++) {
+            T us[H];
+#pragma unroll
+            for (int j = 0; j < H; j++) us[j] = ab[s][j >> 1][j & 1];
+            sink.weight0(s, us, in[0][s], in[1][s]);  // s == 0: + bias
+        }
     }
 };
 

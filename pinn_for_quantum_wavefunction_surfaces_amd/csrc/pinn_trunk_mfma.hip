@@ -1200,6 +1200,7 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, const float* 
         if (mfma_generation() == 1) return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
         return launch2_HL<64, 2, 2, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
     }
+    // (two groups per block = 2 waves/SIMD was tried for 2x128: 436 B/lane of spills, 2.3x slower)
     if (H == 128 && L == 2) return launch2_HL<128, 2, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (H == 64 && L == 4) return launch2_HL<64, 4, 2, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (H == 128 && L == 4) return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);

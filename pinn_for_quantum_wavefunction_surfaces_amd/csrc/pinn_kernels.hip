@@ -406,6 +406,159 @@ __global__ __launch_bounds__(kBlock, PINN_TRUNK_MIN_WAVES) void k_trunk(const fl
 }
 
 // -------------------------------------------------------------- R-only nets
+// ---------------------------------------------------------- 32x32 mat-vec on the matrix pipe
+// y[j] = sum_i M[j][i] x[i] for each lane's own point (x, y: one value per lane per neuron).
+// The 32x32 matrix is the A operand of v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains) and lives
+// in 16 VGPRs for the whole kernel: lane l holds M[l&31][2t + (l>>5)], t = 0..15.  The B operand
+// of step t is (x[2t] of points 0..31 | x[2t+1] of points 0..31): one v_permlane32_swap of the
+// registers x[2t], x[2t+1] yields it for points 0..31 AND, in its second result, for points
+// 32..63.  The two 32x32 results come back to lane = point order with 16 more swaps.  No scalar
+// weight stream, no LDS: the VALU only does the activations.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Mat32 {
+    float w[16];
+};
+
+// v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b.  Inline asm on purpose: hipcc
+// (ROCm 7.2) lowers the SECOND result of __builtin_amdgcn_permlane32_swap to the same register as
+// the first (checked on hardware with gpurun_scratch-style integer tests).  The s_nops are the
+// VALU-write -> permlane-read and permlane-write -> MFMA-read wait states, which the compiler does
+// not pad inside an asm statement.
+__device__ __forceinline__ void swap32(float& a, float& b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
+__device__ __forceinline__ void load_mat32(const float* __restrict__ W, bool transpose, int lane, Mat32& m)
+{
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int r = lane & 31, k = 2 * t + (lane >> 5);
+        m.w[t] = transpose ? W[k * 32 + r] : W[r * 32 + k];
+    }
+}
+
+__device__ __forceinline__ void matvec32(const Mat32& m, const float (&x)[32], float (&y)[32])
+{
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        float b0 = x[2 * t], b1 = x[2 * t + 1];
+        swap32(b0, b1);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(m.w[t], b0, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(m.w[t], b1, a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float q0 = a0[r], q1 = a1[r];
+        swap32(q0, q1);
+        const int j = (r & 3) + 8 * (r >> 2);
+        y[j] = q0;
+        y[j + 4] = q1;
+    }
+}
+
+// E(R) and g(R) with the 32x32 layer on the matrix pipe (HE = 32).  Same mathematics as
+// pinn::Rnet (poc/main.py:249-253,262-264; train.py:48-52).
+template <int HG, int ACT>
+struct RnetM32 {
+    static constexpr int HE = 32;
+    float h1[HE], h2[HE], hg[HG];
+
+    __device__ __forceinline__ void forward(const float* __restrict__ th, const Mat32& M, float R, float& E, float& g)
+    {
+        constexpr RnetLayout Lo{HE, HG};
+        float s1, s2;
+#pragma unroll
+        for (int c0 = 0; c0 < HE; c0 += 16) {
+            float w1[16], b1[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) { w1[j] = th[Lo.WE1() + c0 + j]; b1[j] = th[Lo.bE1() + c0 + j]; }
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < 16; j++) act012<ACT>(w1[j] * R + b1[j], h1[c0 + j], s1, s2);
+            PINN_ROW_FENCE();
+        }
+        {
+            float wg1[HG], bg1[HG], wg2[HG];
+#pragma unroll
+            for (int j = 0; j < HG; j++) { wg1[j] = th[Lo.WG1() + j]; bg1[j] = th[Lo.bG1() + j]; wg2[j] = th[Lo.WG2() + j]; }
+            float gg = th[Lo.bG2()];
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < HG; j++) {
+                act012<ACT>(wg1[j] * R + bg1[j], hg[j], s1, s2);
+                gg += wg2[j] * hg[j];
+            }
+            g = gg;
+            PINN_ROW_FENCE();
+        }
+        float pre[HE];
+        matvec32(M, h1, pre);
+        float e = th[Lo.bE3()];
+#pragma unroll
+        for (int c0 = 0; c0 < HE; c0 += 16) {
+            float b2[16], w3[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) { b2[j] = th[Lo.bE2() + c0 + j]; w3[j] = th[Lo.WE3() + c0 + j]; }
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                act012<ACT>(pre[c0 + j] + b2[j], h2[c0 + j], s1, s2);
+                e += w3[j] * h2[c0 + j];
+            }
+            PINN_ROW_FENCE();
+        }
+        E = e;
+    }
+
+    template <class Sink>
+    __device__ __forceinline__ void backward(const float* __restrict__ th, const Mat32& MT, float R, float Eb,
+                                             float gb, Sink& sink)
+    {
+        constexpr RnetLayout Lo{HE, HG};
+        float a2[HE], t3[HE];
+#pragma unroll
+        for (int c0 = 0; c0 < HE; c0 += 16) {
+            float w3[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) w3[j] = th[Lo.WE3() + c0 + j];
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                t3[c0 + j] = Eb * h2[c0 + j];
+                a2[c0 + j] = Eb * w3[j] * act1_from_value<ACT>(h2[c0 + j]);
+            }
+            PINN_ROW_FENCE();
+        }
+        sink.e3(t3, Eb);
+        sink.e2(a2, h1);
+        float a1[HE];
+        matvec32(MT, a2, a1);
+#pragma unroll
+        for (int i = 0; i < HE; i++) a1[i] *= act1_from_value<ACT>(h1[i]);
+        sink.e1(a1, R);
+        float tg[HG], ag[HG];
+        {
+            float wg2[HG];
+#pragma unroll
+            for (int j = 0; j < HG; j++) wg2[j] = th[Lo.WG2() + j];
+            PINN_ROW_FENCE();
+#pragma unroll
+            for (int j = 0; j < HG; j++) {
+                tg[j] = gb * hg[j];
+                ag[j] = gb * wg2[j] * act1_from_value<ACT>(hg[j]);
+            }
+            PINN_ROW_FENCE();
+        }
+        sink.g2(tg, gb);
+        sink.g1(ag, R);
+    }
+};
+
 template <int HE, int HG, int ACT>
 __global__ __launch_bounds__(kBlock) void k_rnet_fwd(const float* __restrict__ th_r,
                                                      const float* __restrict__ thT_r,
@@ -413,14 +566,32 @@ __global__ __launch_bounds__(kBlock) void k_rnet_fwd(const float* __restrict__ t
                                                      float* __restrict__ E, float* __restrict__ g,
                                                      float* __restrict__ E_user)
 {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * kBlock) {
-        Rnet<HE, HG, ACT, float> rn;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Mat32 M;
+    if (HE == 32) {
+        constexpr RnetLayout Lo{HE, HG};
+        load_mat32(th_r + Lo.WE2(), false, lane, M);
+    }
+    // whole waves stay in the loop together (the matrix-pipe path needs all 64 lanes)
+    for (int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kWave; base < n;
+         base += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = base + lane;
+        const bool valid = i < n;
+        const float Rv = R[valid ? i : n - 1];
         float e, gg;
-        rn.forward(launder(th_r), launder(thT_r), R[i], e, gg);
-        E[i] = e;
-        g[i] = gg;
-        if (E_user) E_user[i] = e;
+        if constexpr (HE == 32) {
+            RnetM32<HG, ACT> rn;
+            rn.forward(launder(th_r), M, Rv, e, gg);
+        } else {
+            Rnet<HE, HG, ACT, float> rn;
+            rn.forward(launder(th_r), launder(thT_r), Rv, e, gg);
+        }
+        if (valid) {
+            E[i] = e;
+            g[i] = gg;
+            if (E_user) E_user[i] = e;
+        }
     }
 }
 
@@ -517,8 +688,9 @@ struct RnetSink {
     }
 };
 
-// two waves per SIMD: the 32-wide mat-vecs do only 8 packed FMAs per 16-float weight chunk, so a
-// second wave is what hides the scalar-load latency (1 wave/SIMD measured 1.8x slower)
+// two waves per SIMD.  Measured at 1M points (HE = 32): 2 waves with MFMA-tile vector sums
+// 124 us; 1 wave with lane-local vector sums 225 us -- this kernel alternates short VALU, LDS and
+// matrix-pipe phases and needs the second wave to fill the gaps.
 template <int HE, int HG, int ACT>
 __global__ __launch_bounds__(kBlock, 2) void k_rnet_bwd(const float* __restrict__ th_r,
                                                      const float* __restrict__ thT_r,
@@ -540,6 +712,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_rnet_bwd(const float* __restrict_
     sink.lane = lane;
     sink.zero();
     for (int k = lane; k < 2 * HR * kPitch; k += kWave) sink.U[k] = 0.0f;
+    Mat32 M, MT;
+    if (HE == 32) {
+        load_mat32(th_r + Lo.WE2(), false, lane, M);
+        load_mat32(th_r + Lo.WE2(), true, lane, MT);
+    }
 
     for (int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kWave; base < n;
          base += (int64_t)gridDim.x * kBlock) {
@@ -548,10 +725,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_rnet_bwd(const float* __restrict_
         const int64_t id = valid ? idx : n - 1;
         const float Rv = R[id];
         const float eb = valid ? Eb[id] : 0.0f, gbv = valid ? gb[id] : 0.0f;
-        Rnet<HE, HG, ACT, float> rn;
         float e, gg;
-        rn.forward(launder(th_r), launder(thT_r), Rv, e, gg);
-        rn.backward(launder(th_r), Rv, eb, gbv, sink);
+        if constexpr (HE == 32) {
+            RnetM32<HG, ACT> rn;
+            rn.forward(launder(th_r), M, Rv, e, gg);
+            rn.backward(launder(th_r), MT, Rv, eb, gbv, sink);
+        } else {
+            Rnet<HE, HG, ACT, float> rn;
+            rn.forward(launder(th_r), launder(thT_r), Rv, e, gg);
+            rn.backward(launder(th_r), Rv, eb, gbv, sink);
+        }
     }
     const float sE3 = wave_sum(sink.bE3), sG2 = wave_sum(sink.bG2);
     for (int w = 0; w < kWavesPerBlock; w++) {

@@ -584,7 +584,8 @@ template <int H, int L, int SPLIT, int WAVES>
 struct M2Cfg {
     static constexpr int HT = H / 16, KC = H / 32, NW = L - 1;
     static constexpr int GROUPS = WAVES / SPLIT;
-    static_assert(H / SPLIT == 32, "each wave owns 32 neurons");
+    static constexpr int RT = H / SPLIT / 16;                     // row tiles (16 neurons) per wave
+    static_assert(RT == 1 || RT == 2, "a wave owns 16 or 32 neurons");
     static constexpr int WPK_ALL = NW * 2 * H * H;                // bf16 elements
     // packed weights are staged in LDS when they fit beside the exchange buffers; otherwise
     // (4x128: 192 KB) the A fragments are read from global memory, where they stay L2-resident
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
 {
     using C = M2Cfg<H, L, SPLIT, WAVES>;
     using Lay = TrunkLayout<H, L>;
-    constexpr int HT = C::HT, KC = C::KC, NW = C::NW, NT = WAVES * 64;
+    constexpr int HT = C::HT, KC = C::KC, NW = C::NW, NT = WAVES * 64, RT = C::RT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __bf16* wpk = reinterpret_cast<__bf16*>(lds_raw);
     float* small = reinterpret_cast<float*>(lds_raw + C::OFF_SMALL);
@@ -627,6 +628,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
     unsigned char* XB = gbase;                          // [(L-1)] exchange buffers: outputs of layers 0..L-2
     unsigned char* YB = gbase + (size_t)(L - 1) * C::EB; // adjoint exchange buffer
     float* SB = reinterpret_cast<float*>(YB + C::EB);   // [SPLIT][16][2]
+    // this wave's piece of B fragment (k-chunk, stream s): all 16 bytes (RT = 2) or one 8-byte half
+    const int own_kc = (RT * part) >> 1, own_half = (RT * part) & 1;
+    auto put_own = [&](unsigned char* eb, int s, const u32x4& v) {
+        unsigned char* p = eb + ((size_t)(own_kc * 5 + s) * 64 + lane) * 16;
+        if (RT == 2) *reinterpret_cast<u32x4*>(p) = v;
+        else *reinterpret_cast<u32x2*>(p + 8 * own_half) = u32x2{v[0], v[1]};
+    };
 
     {
         if (C::WLDS) {
@@ -647,19 +655,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
     __syncthreads();
     const __bf16* wsrc = C::WLDS ? wpk : wpk_g;   // one provenance per instantiation
 
-    // ---- persistent gradient state (own 32 neurons = row tiles 2*part, 2*part+1)
-    f32x4 wacc[NW][2][HT];
-    f32x4 bacc[L][2], w0acc[2][2], woacc[2];
+    // ---- persistent gradient state (own row tiles RT*part + tt, tt < RT)
+    f32x4 wacc[NW][RT][HT];
+    f32x4 bacc[L][RT], w0acc[RT][2], woacc[RT];
     float acc_bout = 0.f, acc_pde = 0.f, acc_bc1 = 0.f, acc_bc2 = 0.f;
     if (MODE == MODE_BWD) {
 #pragma unroll
         for (int l = 0; l < NW; l++)
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+            for (int t = 0; t < RT; t++)
 #pragma unroll
                 for (int b = 0; b < HT; b++) wacc[l][t][b] = splat(0.f);
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
+        for (int t = 0; t < RT; t++) {
 #pragma unroll
             for (int l = 0; l < L; l++) bacc[l][t] = splat(0.f);
             w0acc[t][0] = splat(0.f); w0acc[t][1] = splat(0.f); woacc[t] = splat(0.f);
@@ -709,12 +717,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                 in[1][s] = useB ? inA[0][s] : inA[1][s];
             }
             // =========================== forward ===========================
-            u32x2 sv[NW][2][5];  // saved (h, a_x, a_y, a_z, a_lap) of the own neurons, layers 1..L-1
+            u32x2 sv[NW][RT][5];  // saved (h, a_x, a_y, a_z, a_lap) of the own neurons, layers 1..L-1
             {   // ---- layer 0 on the VALU (K = 2), own neurons only
                 u32x4 xo[5];
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++) {
-                    const int n0 = 32 * part + 16 * tt + 4 * g;
+                for (int tt = 0; tt < RT; tt++) {
+                    const int n0 = 16 * (RT * part + tt) + 4 * g;
                     const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2);
                     const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2 + 4);
                     const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
@@ -730,13 +738,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
                         const u32x2 p = pack4(o[s]);
-                        if (tt) { xo[s][2] = p[0]; xo[s][3] = p[1]; }
-                        else { xo[s][0] = p[0]; xo[s][1] = p[1]; }
+                        xo[s][2 * tt] = p[0]; xo[s][2 * tt + 1] = p[1];
                     }
                 }
 #pragma unroll
-                for (int s = 0; s < 5; s++)
-                    *reinterpret_cast<u32x4*>(XB + ((size_t)(part * 5 + s) * 64 + lane) * 16) = xo[s];
+                for (int s = 0; s < 5; s++) put_own(XB, s, xo[s]);
             }
             __syncthreads();
             float Sv = 0.f, Sl = 0.f;
@@ -744,29 +750,29 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
             for (int l = 1; l < L; l++) {
                 const __bf16* wf = wsrc + (size_t)((l - 1) * 2 + 0) * H * H;
                 const unsigned char* xin = XB + (size_t)(l - 1) * C::EB;
-                f32x4 a[2][5];
+                f32x4 a[RT][5];
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++) {
-                    a[tt][0] = *reinterpret_cast<const f32x4*>(sbl + (l - 1) * H + 32 * part + 16 * tt + 4 * g);
+                for (int tt = 0; tt < RT; tt++) {
+                    a[tt][0] = *reinterpret_cast<const f32x4*>(sbl + (l - 1) * H + 16 * (RT * part + tt) + 4 * g);
 #pragma unroll
                     for (int s = 1; s < 5; s++) a[tt][s] = splat(0.f);
                 }
 #pragma unroll
                 for (int kc = 0; kc < KC; kc++) {
-                    bf16x8 wa[2];
+                    bf16x8 wa[RT];
 #pragma unroll
-                    for (int tt = 0; tt < 2; tt++)
-                        wa[tt] = *reinterpret_cast<const bf16x8*>(wf + (((2 * part + tt) * KC + kc) * 64 + lane) * 8);
+                    for (int tt = 0; tt < RT; tt++)
+                        wa[tt] = *reinterpret_cast<const bf16x8*>(wf + (((RT * part + tt) * KC + kc) * 64 + lane) * 8);
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
                         const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xin + ((size_t)(kc * 5 + s) * 64 + lane) * 16);
 #pragma unroll
-                        for (int tt = 0; tt < 2; tt++) a[tt][s] = mfma(wa[tt], xb, a[tt][s]);
+                        for (int tt = 0; tt < RT; tt++) a[tt][s] = mfma(wa[tt], xb, a[tt][s]);
                     }
                 }
                 u32x4 xo[5];
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++) {
+                for (int tt = 0; tt < RT; tt++) {
                     f32x4 s0, s1, s2;
                     act012v<ACT>(a[tt][0], s0, s1, s2);
                     const f32x4 q = a[tt][1] * a[tt][1] + a[tt][2] * a[tt][2] + a[tt][3] * a[tt][3];
@@ -779,11 +785,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
 #pragma unroll
                         for (int s = 0; s < 5; s++) {
                             const u32x2 p = pack4(o[s]);
-                            if (tt) { xo[s][2] = p[0]; xo[s][3] = p[1]; }
-                            else { xo[s][0] = p[0]; xo[s][1] = p[1]; }
+                            xo[s][2 * tt] = p[0]; xo[s][2 * tt + 1] = p[1];
                         }
                     } else {
-                        const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 32 * part + 16 * tt + 4 * g);
+                        const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 16 * (RT * part + tt) + 4 * g);
                         const f32x4 pv = wo * s0, pl = wo * ol;
                         Sv += (pv[0] + pv[1]) + (pv[2] + pv[3]);
                         Sl += (pl[0] + pl[1]) + (pl[2] + pl[3]);
@@ -792,8 +797,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                 if (l < L - 1) {
                     unsigned char* xout = XB + (size_t)l * C::EB;
 #pragma unroll
-                    for (int s = 0; s < 5; s++)
-                        *reinterpret_cast<u32x4*>(xout + ((size_t)(part * 5 + s) * 64 + lane) * 16) = xo[s];
+                    for (int s = 0; s < 5; s++) put_own(xout, s, xo[s]);
                     __syncthreads();
                 }
             }
@@ -834,7 +838,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
             {   // ---- last hidden layer, own neurons
                 u32x4 yo[5];
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++) {
+                for (int tt = 0; tt < RT; tt++) {
                     const f32x4 h = unpack4(sv[NW - 1][tt][0]);
                     f32x4 a[5];
 #pragma unroll
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                     f32x4 s1, s2, s3;
                     act123v<ACT>(h, s1, s2, s3);
                     const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
-                    const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 32 * part + 16 * tt + 4 * g);
+                    const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 16 * (RT * part + tt) + 4 * g);
                     woacc[tt] += cv * h + cl * (s1 * a[4] + s2 * q);
                     const f32x4 o0 = cv * wo, ol = cl * wo;
                     const f32x4 u = 2.0f * s2 * ol;
@@ -856,13 +860,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
                         const u32x2 p = pack4(ab[s]);
-                        if (tt) { yo[s][2] = p[0]; yo[s][3] = p[1]; }
-                        else { yo[s][0] = p[0]; yo[s][1] = p[1]; }
+                        yo[s][2 * tt] = p[0]; yo[s][2 * tt + 1] = p[1];
                     }
                 }
 #pragma unroll
-                for (int s = 0; s < 5; s++)
-                    *reinterpret_cast<u32x4*>(YB + ((size_t)(part * 5 + s) * 64 + lane) * 16) = yo[s];
+                for (int s = 0; s < 5; s++) put_own(YB, s, yo[s]);
             }
             __syncthreads();
 #pragma unroll
@@ -897,8 +899,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                         fx[it] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     }
 #pragma unroll
-                    for (int tt = 0; tt < 2; tt++) {
-                        const int T = 2 * part + tt;
+                    for (int tt = 0; tt < RT; tt++) {
+                        const int T = RT * part + tt;
                         const size_t toff = ((size_t)(T >> 1) * 5 * 64 + (size_t)(2 * (T & 1)) * 16) * 16 + chunk;
                         const bool z0 = ay[0] == zero, z1 = ay[1] == zero;
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
@@ -912,37 +914,38 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                 }
                 // ---- adjoint of layer l's input for the own neurons, then layer l-1's activation adjoint
                 const __bf16* wb = wsrc + (size_t)((l - 1) * 2 + 1) * H * H;
-                f32x4 ob[2][5];
+                f32x4 ob[RT][5];
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++)
+                for (int tt = 0; tt < RT; tt++)
 #pragma unroll
                     for (int s = 0; s < 5; s++) ob[tt][s] = splat(0.f);
 #pragma unroll
                 for (int kc = 0; kc < KC; kc++) {
-                    bf16x8 wa[2];
+                    bf16x8 wa[RT];
 #pragma unroll
-                    for (int tt = 0; tt < 2; tt++)
-                        wa[tt] = *reinterpret_cast<const bf16x8*>(wb + (((2 * part + tt) * KC + kc) * 64 + lane) * 8);
+                    for (int tt = 0; tt < RT; tt++)
+                        wa[tt] = *reinterpret_cast<const bf16x8*>(wb + (((RT * part + tt) * KC + kc) * 64 + lane) * 8);
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
                         const bf16x8 yb = *reinterpret_cast<const bf16x8*>(YB + ((size_t)(kc * 5 + s) * 64 + lane) * 16);
 #pragma unroll
-                        for (int tt = 0; tt < 2; tt++) ob[tt][s] = mfma(wa[tt], yb, ob[tt][s]);
+                        for (int tt = 0; tt < RT; tt++) ob[tt][s] = mfma(wa[tt], yb, ob[tt][s]);
                     }
                 }
                 u32x4 yo[5];
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++) {
+                for (int tt = 0; tt < RT; tt++) {
                     f32x4 h, a[5];
                     if (l - 1 == 0) {
-                        const int n0 = 32 * part + 16 * tt + 4 * g;
+                        const int n0 = 16 * (RT * part + tt) + 4 * g;
                         const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2);
                         const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2 + 4);
                         const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
 #pragma unroll
                         for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
-                        const u32x4 hx = *reinterpret_cast<const u32x4*>(XB + ((size_t)(part * 5 + 0) * 64 + lane) * 16);
-                        h = unpack4(tt ? u32x2{hx[2], hx[3]} : u32x2{hx[0], hx[1]});
+                        const int Tn = RT * part + tt;
+                        const u32x4 hx = *reinterpret_cast<const u32x4*>(XB + ((size_t)((Tn >> 1) * 5 + 0) * 64 + lane) * 16);
+                        h = unpack4((Tn & 1) ? u32x2{hx[2], hx[3]} : u32x2{hx[0], hx[1]});
                     } else {
                         h = unpack4(sv[l - 2][tt][0]);
 #pragma unroll
@@ -970,16 +973,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
 #pragma unroll
                         for (int s = 0; s < 5; s++) {
                             const u32x2 p = pack4(ab[s]);
-                            if (tt) { yo[s][2] = p[0]; yo[s][3] = p[1]; }
-                            else { yo[s][0] = p[0]; yo[s][1] = p[1]; }
+                            yo[s][2 * tt] = p[0]; yo[s][2 * tt + 1] = p[1];
                         }
                     }
                 }
                 if (l - 1 >= 1) {   // hand the next layer's adjoints to the group
                     __syncthreads();   // everyone is done reading YB
 #pragma unroll
-                    for (int s = 0; s < 5; s++)
-                        *reinterpret_cast<u32x4*>(YB + ((size_t)(part * 5 + s) * 64 + lane) * 16) = yo[s];
+                    for (int s = 0; s < 5; s++) put_own(YB, s, yo[s]);
                     __syncthreads();
                 }
             }
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                 s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
     if (MODE == MODE_BWD) {
 #pragma unroll
-        for (int tt = 0; tt < 2; tt++)
+        for (int tt = 0; tt < RT; tt++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -1018,20 +1019,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
 #pragma unroll
             for (int l = 1; l < L; l++)
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++)
+                for (int tt = 0; tt < RT; tt++)
 #pragma unroll
                     for (int it = 0; it < HT; it++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const int nj = q_neuron(16 * (2 * part + tt) + 4 * g + r), ni = q_neuron(16 * it + c);
+                            const int nj = q_neuron(16 * (RT * part + tt) + 4 * g + r), ni = q_neuron(16 * it + c);
                             out[Lay::W(l) + nj * H + ni] = wacc[l - 1][tt][it][r];
                         }
             if (c == 0) {
 #pragma unroll
-                for (int tt = 0; tt < 2; tt++)
+                for (int tt = 0; tt < RT; tt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int nj = 32 * part + 16 * tt + 4 * g + r;
+                        const int nj = 16 * (RT * part + tt) + 4 * g + r;
 #pragma unroll
                         for (int l = 0; l < L; l++) out[Lay::b(l) + nj] = bacc[l][tt][r];
                         out[Lay::W(0) + 2 * nj] = w0acc[tt][0][r];
@@ -1065,20 +1066,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
 #pragma unroll
                 for (int l = 1; l < L; l++)
 #pragma unroll
-                    for (int tt = 0; tt < 2; tt++)
+                    for (int tt = 0; tt < RT; tt++)
 #pragma unroll
                         for (int it = 0; it < HT; it++)
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
-                                const int nj = q_neuron(16 * (2 * part + tt) + 4 * g + r), ni = q_neuron(16 * it + c);
+                                const int nj = q_neuron(16 * (RT * part + tt) + 4 * g + r), ni = q_neuron(16 * it + c);
                                 gimg[Lay::W(l) + nj * H + ni] += wacc[l - 1][tt][it][r];
                             }
                 if (c == 0) {
 #pragma unroll
-                    for (int tt = 0; tt < 2; tt++)
+                    for (int tt = 0; tt < RT; tt++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const int nj = 32 * part + 16 * tt + 4 * g + r;
+                            const int nj = 16 * (RT * part + tt) + 4 * g + r;
 #pragma unroll
                             for (int l = 0; l < L; l++) gimg[Lay::b(l) + nj] += bacc[l][tt][r];
                             gimg[Lay::W(0) + 2 * nj] += w0acc[tt][0][r];
@@ -1174,15 +1175,13 @@ bool launch_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, co
 
 bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
 
-// H = 64 can run either generation.  Measured (1M points, 2x64 tanh, symmetric): point-split
-// 0.90 ms, neuron-split 1.02 ms, so the first generation is the default there; PINN_MFMA_GEN=2
-// selects the neuron-split kernel for A/B measurements.  H = 128 only exists as neuron-split.
+// A/B switch for measurements (see launch_trunk_mfma): PINN_MFMA_GEN = 1 (default), 2, 3.
 static int mfma_generation()
 {
     static int gen = -1;
     if (gen < 0) {
         const char* e = getenv("PINN_MFMA_GEN");
-        gen = (e && e[0] == '2') ? 2 : 1;
+        gen = (e && e[0] >= '1' && e[0] <= '9') ? e[0] - '0' : 1;
     }
     return gen;
 }
@@ -1196,13 +1195,29 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, const float* 
                        hipError_t* err)
 {
     __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
+    // <H, L, SPLIT, WAVES>: SPLIT waves share a 16-point tile, WAVES per block.  Defaults are the
+    // fastest measured decomposition per shape (1M points, MI355X, kernel ms):
+    //   2x64 : point-split gen-1 0.90-0.95 | <2,8> 1.11 | <4,8> 0.97
+    //   2x128: <8,8> 2.57 | <4,4> 2.73          4x64: <2,4> 2.37 | <4,8> 4.20
+    //   4x128: <4,4> 27.6 | <8,8> 29.8  (both spill > 1 KB/lane: functional, not tuned)
+    // PINN_MFMA_GEN=2/3 selects the alternatives for A/B measurements.
+    const int gen = mfma_generation();
     if (H == 64 && L == 2) {
-        if (mfma_generation() == 1) return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
-        return launch2_HL<64, 2, 2, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+        if (gen == 2) return launch2_HL<64, 2, 2, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+        if (gen == 3) return launch2_HL<64, 2, 4, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+        return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
     }
-    // (two groups per block = 2 waves/SIMD was tried for 2x128: 436 B/lane of spills, 2.3x slower)
-    if (H == 128 && L == 2) return launch2_HL<128, 2, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-    if (H == 64 && L == 4) return launch2_HL<64, 4, 2, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-    if (H == 128 && L == 4) return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+    if (H == 128 && L == 2) {
+        if (gen == 2) return launch2_HL<128, 2, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+        return launch2_HL<128, 2, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+    }
+    if (H == 64 && L == 4) {
+        if (gen == 2) return launch2_HL<64, 4, 4, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+        return launch2_HL<64, 4, 2, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+    }
+    if (H == 128 && L == 4) {
+        if (gen == 2) return launch2_HL<128, 4, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+        return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+    }
     return false;
 }

@@ -398,3 +398,35 @@ def test_reference_style_train_driver_runs(tmp_path):
     assert hist["Ltot"][-1, 0] < 0.5 * hist["Ltot"][0, 0]
     pkg.saveLoss(params, hist)
     assert os.path.getsize(params["lossPath"]) > 0
+
+
+def test_energy_from_psi_matches_oracle_quadrature(golden_dir):
+    """<psi|H|psi>/<psi|psi> (poc/main.py:438-464) from the fused forward + on-device Simpson vs
+    the same quadrature of the oracle's psi, H psi with scipy.integrate.simpson on the host.
+    Both an odd and an even point count (scipy treats the last interval of even counts
+    specially).  The reference's stored E_int table is not reproducible from its stated
+    settings, so it only serves as a 5e-3 sanity band at n_test = 80."""
+    from scipy.integrate import simpson
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))["fineTune"]
+    e = np.load(os.path.join(golden_dir, "g5_energy.npz"))
+    params = pkg.set_params()
+    model = pkg.NN_ion(params).to(DEV)
+    model.load_flat_params(torch.tensor(w))
+    A, Hm = O.arch(), O.ham_A()
+    for n in (21, 24):
+        params["n_test"] = n
+        ax = np.linspace(-18, 18, n)
+        X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+        fw = O.forward(A, Hm, w, X.ravel(), Y.ravel(), Z.ravel(), np.full(n ** 3, 1.0))
+        psi = fw["psi"].reshape(n, n, n)
+        hpsi = (fw["res"] + fw["E"] * fw["psi"]).reshape(n, n, n)
+        I3 = lambda f: simpson([simpson([simpson(fx, x=ax) for fx in fy], x=ax) for fy in f], x=ax)
+        ref = I3(psi * hpsi) / I3(psi * psi)
+        got, E_net = pkg.energy_from_psi(1.0, params, model)
+        assert abs(got - ref) < 2e-5 * abs(ref), (n, got, ref)
+        assert abs(E_net - fw["E"][-1]) < 1e-5
+    params["n_test"] = 80                                  # the reference's default (poc/main.py:40)
+    E80, _ = pkg.energy_from_psi(1.0, params, model)
+    k = int(np.argmin(np.abs(e["R"] - 1.0)))
+    assert abs(E80 - e["E_int"][k]) < 5e-3                 # stored -1.09366; n_test 80 gives -1.0948
+    assert abs(pkg.energy_from_psi_LCAO(1.0, params) - e["Elcao"][k]) < 5e-3

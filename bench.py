@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--points", type=int, default=1000000, help="points per GPU per step")
     ap.add_argument("--arch", choices=sorted(ARCHS), default=DEFAULT_ARCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one captured HIP graph (helps below ~10^5 points)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,16 +143,22 @@ def main():
     def run(model, arch_name):
         """W untimed + K timed steps of one workload; returns (seconds, trunk kernel ms, losses)"""
         tr = pkg.Trainer(model, params, n_points=args.points, lr=8e-3, seed=12345, device=dev, plan=plan)
-        tr.h.profile_enable(min(max(args.steps, 1), 1024))
-        for _ in range(args.warmup):
-            tr.step()
+        if args.graph:
+            step = tr.capture_graph(warmup=max(args.warmup, 1))
+            tr.h.profile_enable(1)          # events recorded at capture time only
+        else:
+            step = tr.step
+            tr.h.profile_enable(min(max(args.steps, 1), 1024))
+            for _ in range(args.warmup):
+                step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            tr.step()
+            step()
         barrier()
         dt = plan.max_over_ranks(time.perf_counter() - t0, dev)
-        return dt, tr.h.profile_read(min(args.steps, 1024)), tr.losses()
+        kms = float("nan") if args.graph else tr.h.profile_read(min(args.steps, 1024))
+        return dt, kms, tr.losses()
 
     dt, trunk_ms, (Ltot, Lpde, Lbc) = run(model, args.arch)
     # the other workload rides along as a secondary record (same K, W, points)

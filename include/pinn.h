@@ -88,11 +88,14 @@ const char *pinn_last_error(const pinn_handle *h);
  * seed); x,y,z ~ U(-box,box), R ~ U(Rlo,Rhi); x := cutoff where either
  * pre-clamp radius < cutoff; mask bit0: r1 >= bc_cutoff, bit1: r2 >= bc_cutoff
  * (post-clamp).  counts (device int64[2], may be NULL) receives the two BC set
- * sizes of THIS call.  A rank of a data-parallel job passes its own `first`. */
-int pinn_sample(pinn_handle *h, uint64_t seed, uint64_t step, int64_t first, int64_t n,
-                float box, float Rlo, float Rhi, float cutoff, float bc_cutoff,
-                float *x, float *y, float *z, float *R, uint8_t *mask, int64_t *counts,
-                void *stream);
+ * sizes of THIS call.  A rank of a data-parallel job passes its own `first`.
+ * step_dev (device int32[1], may be NULL): when given, the Philox step is step + *step_dev,
+ * read on the device -- pass pinn_adam's step counter so that a captured HIP graph of the whole
+ * training step draws fresh points on every replay. */
+int pinn_sample(pinn_handle *h, uint64_t seed, uint64_t step, const int32_t *step_dev,
+                int64_t first, int64_t n, float box, float Rlo, float Rhi, float cutoff,
+                float bc_cutoff, float *x, float *y, float *z, float *R, uint8_t *mask,
+                int64_t *counts, void *stream);
 
 /* Replaces NN_ion.forward + lapl/hamiltonian (poc/main.py:247-267,82-120,345)
  * and train.py:41-54 evaluated without a graph.  Outputs (each n floats, any

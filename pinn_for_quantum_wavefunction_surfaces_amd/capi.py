@@ -61,7 +61,7 @@ def load_library():
     lib.pinn_destroy.argtypes = [vp]
     lib.pinn_last_error.restype = C.c_char_p
     lib.pinn_last_error.argtypes = [vp]
-    lib.pinn_sample.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64] + \
+    lib.pinn_sample.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_int64, C.c_int64] + \
         [C.c_float] * 5 + [fp] * 4 + [vp, i64p, vp]
     lib.pinn_forward.argtypes = [vp] + [fp] * 5 + [C.c_int64, C.POINTER(Ham)] + [fp] * 4 + [vp]
     lib.pinn_residual_fwd_bwd.argtypes = [vp] + [fp] * 5 + [vp, C.c_int64, C.POINTER(Ham), i64p,
@@ -137,8 +137,8 @@ class Handle:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def sample(self, seed, step, first, n, box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
-               counts):
-        self._check(self.lib.pinn_sample(self.h, seed, step, first, n, box, Rlo, Rhi, cutoff,
+               counts, step_dev=None):
+        self._check(self.lib.pinn_sample(self.h, seed, step, _ptr(step_dev), first, n, box, Rlo, Rhi, cutoff,
                                          bc_cutoff, _ptr(x), _ptr(y), _ptr(z), _ptr(R), _ptr(mask),
                                          _ptr(counts), self._stream()), "pinn_sample")
 

@@ -852,7 +852,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
-__global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t step, int64_t first,
+__global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t step0,
+                                                   const int32_t* __restrict__ step_dev, int64_t first,
                                                    int64_t n, float box, float Rlo, float Rhi,
                                                    float cutoff, float bc_cutoff,
                                                    float* __restrict__ x, float* __restrict__ y,
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t step,
                                                    uint8_t* __restrict__ mask,
                                                    unsigned long long* __restrict__ counts)
 {
+    const uint64_t step = step0 + (step_dev ? (uint64_t)(int64_t)*step_dev : 0);
     const float two_box = box + box, dR = Rhi - Rlo;
     const float cut2 = cutoff * cutoff, bc2 = bc_cutoff * bc_cutoff;
     unsigned c1 = 0, c2 = 0;
@@ -1322,15 +1324,16 @@ extern "C" int pinn_adam(pinn_handle* h, float* theta, const float* grad, float*
     return PINN_OK;
 }
 
-extern "C" int pinn_sample(pinn_handle* h, uint64_t seed, uint64_t step, int64_t first, int64_t n,
-                           float box, float Rlo, float Rhi, float cutoff, float bc_cutoff, float* x,
-                           float* y, float* z, float* R, uint8_t* mask, int64_t* counts, void* stream)
+extern "C" int pinn_sample(pinn_handle* h, uint64_t seed, uint64_t step, const int32_t* step_dev,
+                           int64_t first, int64_t n, float box, float Rlo, float Rhi, float cutoff,
+                           float bc_cutoff, float* x, float* y, float* z, float* R, uint8_t* mask,
+                           int64_t* counts, void* stream)
 {
     if (!h) return PINN_ERR_ARG;
     if (!x || !y || !z || !R || n < 1 || first < 0) return fail(h, PINN_ERR_ARG, "null pointer or bad range");
     hipStream_t st = (hipStream_t)stream;
     if (counts) HIPCHK(h, hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), st));
-    hipLaunchKernelGGL(k_sample, dim3(grid_for(n, 512)), dim3(kBlock), 0, st, seed, step, first, n,
+    hipLaunchKernelGGL(k_sample, dim3(grid_for(n, 512)), dim3(kBlock), 0, st, seed, step, step_dev, first, n,
                        box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
                        (unsigned long long*)counts);
     hipError_t e = hipGetLastError();

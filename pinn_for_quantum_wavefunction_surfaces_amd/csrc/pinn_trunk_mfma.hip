@@ -1113,8 +1113,12 @@ hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int gr
     size_t lds = C::LDS_BYTES;
     const size_t need = C::GROUPS == 1 ? 64 : (size_t)(TrunkLayout<H, L>::size + 16) * 4;
     if (lds < need) lds = need;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static bool attr_set = false;   // once per instantiation: not a stream operation (graph capture)
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, theta, (const __bf16*)wpk, A);
     return hipGetLastError();
 }
@@ -1148,8 +1152,12 @@ hipError_t launch_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int gri
     size_t lds = C::LDS_BYTES;
     const size_t need = (size_t)(TrunkLayout<H, L>::size + 16) * 4;
     if (lds < need) lds = need;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static bool attr_set = false;   // once per instantiation: not a stream operation (graph capture)
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, theta, (const __bf16*)wpk, A);
     return hipGetLastError();
 }

@@ -430,3 +430,28 @@ def test_energy_from_psi_matches_oracle_quadrature(golden_dir):
     k = int(np.argmin(np.abs(e["R"] - 1.0)))
     assert abs(E80 - e["E_int"][k]) < 5e-3                 # stored -1.09366; n_test 80 gives -1.0948
     assert abs(pkg.energy_from_psi_LCAO(1.0, params) - e["Elcao"][k]) < 5e-3
+
+
+def test_graph_replay_equals_eager_steps(golden_dir):
+    """the whole step as one captured HIP graph: same trajectory as eager launches, bit for bit,
+    and fresh points on every replay (the Philox step is read from the device-side counter)"""
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))["ionHsym"]
+    params = pkg.set_params()
+
+    def make():
+        m = pkg.NN_ion(params).to(DEV)
+        m.load_flat_params(torch.tensor(w))
+        return pkg.Trainer(m, params, n_points=20000, lr=8e-3, device=DEV)
+
+    a, b = make(), make()
+    for _ in range(8):
+        a.step()
+    replay = b.capture_graph(warmup=3)        # 3 eager steps inside + 1 captured (not run)
+    xs = []
+    for _ in range(5):
+        replay()
+        xs.append(b.x[:4].clone())
+    torch.cuda.synchronize()
+    assert int(a.step_count.item()) == int(b.step_count.item()) == 8
+    assert torch.equal(a.theta, b.theta) and torch.equal(a.grad, b.grad)
+    assert not torch.equal(xs[0], xs[1]) and not torch.equal(xs[3], xs[4])

@@ -56,6 +56,9 @@ ARCHS["wide4x128"] = dict(H=128, L=4, HE=32, HG=10, act=1, n_pass=2, out_scale=1
                           act_name="tanh", peak=2500.0, dtype="bf16",
                           label="4x128 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "
                                 "accumulate, seeded random init")
+ARCHS["wide64x3"] = dict(ARCHS["wide64"], precision="bf16x3", dtype="bf16x3",
+                         label="2x64 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
+                               "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
 DEFAULT_ARCH = "wide64"
 
 

@@ -28,6 +28,7 @@ size_t mfma_packed_weight_bytes(int H, int L);
 bool mfma_trunk_supported(int H, int L);
 int mfma_partial_stride(int H, int L);   // floats per block partial row (trunk grads + 3)
 // enqueue pack + trunk kernel; returns false when (H, L, act, npass, mode) has no instantiation
-bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, const float* theta,
+bool mfma_x3_supported(int H, int L);
+bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, const float* theta,
                        void* packed_weights, const TrunkArgs& A, int grid, hipStream_t st,
                        hipError_t* err);

@@ -1099,7 +1099,8 @@ static int run_trunk(pinn_handle* h, int mode, const float* theta, const TrunkAr
         const TrunkKey k{a.H, a.L, a.act, a.n_pass, mode};
         return launch_trunk(k, theta, h->thT, A, grid, st, e);
     }
-    return launch_trunk_mfma(a.H, a.L, a.act, a.n_pass, mode, theta, h->wpk, A, grid, st, e) ? 1 : 0;
+    return launch_trunk_mfma(a.H, a.L, a.act, a.n_pass, mode, a.precision == PINN_PREC_BF16X3, theta, h->wpk, A,
+                             grid, st, e) ? 1 : 0;
 }
 
 extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points, pinn_handle** out)
@@ -1111,6 +1112,8 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
         if (!trunk_supported(arch->H, arch->L)) return PINN_ERR_UNSUPPORTED;
     } else if (arch->precision == PINN_PREC_BF16) {
         if (!mfma_trunk_supported(arch->H, arch->L)) return PINN_ERR_UNSUPPORTED;
+    } else if (arch->precision == PINN_PREC_BF16X3) {
+        if (!mfma_x3_supported(arch->H, arch->L)) return PINN_ERR_UNSUPPORTED;
     } else {
         return PINN_ERR_UNSUPPORTED;
     }

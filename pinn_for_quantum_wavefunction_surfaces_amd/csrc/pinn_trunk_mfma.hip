@@ -70,7 +70,8 @@ struct MCfg {
 // ------------------------------------------------------------------ weight pack
 // fwd: element j of lane (g, row) of fragment (jt, kc) = W[16jt + row][slot_neuron(kc, g, j)]
 // bwd: ...                                            = W[slot_neuron(kc, g, j)][16it + row]
-template <int H, int L>
+// X3: a second plane with the bf16 of the remainder w - bf16(w) follows the first one
+template <int H, int L, bool X3 = false>
 __global__ void k_pack_weights(const float* __restrict__ theta, __bf16* __restrict__ out)
 {
     using C = MCfg<H, L>;
@@ -82,14 +83,17 @@ __global__ void k_pack_weights(const float* __restrict__ theta, __bf16* __restri
     const int lane = f & 63, kc = (f >> 6) % C::KC, tt = (f >> 6) / C::KC;
     const int g = lane >> 4, row = lane & 15;
     const float* W = theta + Lay::W(l);
-    bf16x8 v;
+    bf16x8 v, vlo;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int kn = slot_neuron(kc, g, j);
         const float w = dir == 0 ? W[(16 * tt + row) * H + kn] : W[kn * H + 16 * tt + row];
         v[j] = (__bf16)w;
+        vlo[j] = (__bf16)(w - (float)v[j]);
     }
+    const size_t plane = (size_t)C::NW * 2 * H * H;
     *reinterpret_cast<bf16x8*>(out + ((size_t)((l - 1) * 2 + dir) * H * H) + (size_t)f * 8) = v;
+    if (X3) *reinterpret_cast<bf16x8*>(out + plane + ((size_t)((l - 1) * 2 + dir) * H * H) + (size_t)f * 8) = vlo;
 }
 
 // ------------------------------------------------------------------ small helpers
@@ -101,6 +105,9 @@ __device__ __forceinline__ u32x2 pack4(f32x4 v)  // 4 fp32 -> 4 bf16 (round to n
     return __builtin_bit_cast(u32x2, b);
 }
 
+// hi = bf16(v), lo = bf16(v - hi): hi + lo carries 16 mantissa bits of v
+__device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo);
+
 __device__ __forceinline__ f32x4 unpack4(u32x2 p)
 {
     f32x4 r;
@@ -109,6 +116,12 @@ __device__ __forceinline__ f32x4 unpack4(u32x2 p)
     r[2] = __builtin_bit_cast(float, p[1] << 16);
     r[3] = __builtin_bit_cast(float, p[1] & 0xffff0000u);
     return r;
+}
+
+__device__ __forceinline__ void split4(f32x4 v, u32x2& hi, u32x2& lo)
+{
+    hi = pack4(v);
+    lo = pack4(v - unpack4(hi));
 }
 
 template <int ACT>
@@ -580,19 +593,21 @@ __global__ __launch_bounds__(kBlock, 1) void k_trunk_mfma(const float* __restric
 // [column][neuron] image of the weight-gradient contraction (ds_read_b64_tr_b16 straight
 // from the exchange buffer: no extra image writes).  Workgroup barriers separate the
 // exchange steps; all groups of a block run the same trip count so barriers always match.
-template <int H, int L, int SPLIT, int WAVES>
+template <int H, int L, int SPLIT, int WAVES, bool X3 = false>
 struct M2Cfg {
     static constexpr int HT = H / 16, KC = H / 32, NW = L - 1;
     static constexpr int GROUPS = WAVES / SPLIT;
     static constexpr int RT = H / SPLIT / 16;                     // row tiles (16 neurons) per wave
     static_assert(RT == 1 || RT == 2, "a wave owns 16 or 32 neurons");
-    static constexpr int WPK_ALL = NW * 2 * H * H;                // bf16 elements
+    static constexpr int NPL = X3 ? 2 : 1;                        // operand planes (hi, lo)
+    static constexpr int WPK_ALL = NPL * NW * 2 * H * H;          // bf16 elements
     // packed weights are staged in LDS when they fit beside the exchange buffers; otherwise
     // (4x128: 192 KB) the A fragments are read from global memory, where they stay L2-resident
     static constexpr bool WLDS = (size_t)WPK_ALL * 2 <= 64 * 1024;
     static constexpr int WPK = WLDS ? WPK_ALL : 0;
     static constexpr int NSMALL = 3 * H + NW * H + H + 4;         // floats
-    static constexpr int EB = KC * 5 * 64 * 16;                   // bytes of one exchange buffer
+    static constexpr int EB1 = KC * 5 * 64 * 16;                  // bytes of one plane of an exchange buffer
+    static constexpr int EB = NPL * EB1;
     static constexpr int SBYTES = SPLIT * 16 * 2 * 4;             // per-group partial (Sv, Sl)
     static constexpr int GBYTES = (L - 1) * EB + EB + SBYTES;     // XB[0..L-2], YB, S
     static constexpr int ZBYTES = 1024;
@@ -602,14 +617,16 @@ struct M2Cfg {
     static constexpr size_t LDS_BYTES = OFF_GRP + (size_t)GROUPS * GBYTES;
 };
 
-template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES>
+template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES, bool X3>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const float* __restrict__ theta,
                                                                       const __bf16* __restrict__ wpk_g,
                                                                       TrunkArgs A)
 {
-    using C = M2Cfg<H, L, SPLIT, WAVES>;
+    using C = M2Cfg<H, L, SPLIT, WAVES, X3>;
     using Lay = TrunkLayout<H, L>;
     constexpr int HT = C::HT, KC = C::KC, NW = C::NW, NT = WAVES * 64, RT = C::RT;
+    constexpr size_t WPLANE = (size_t)NW * 2 * H * H;   // elements of one weight plane
+    constexpr int EB1 = C::EB1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __bf16* wpk = reinterpret_cast<__bf16*>(lds_raw);
     float* small = reinterpret_cast<float*>(lds_raw + C::OFF_SMALL);
@@ -634,6 +651,26 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
         unsigned char* p = eb + ((size_t)(own_kc * 5 + s) * 64 + lane) * 16;
         if (RT == 2) *reinterpret_cast<u32x4*>(p) = v;
         else *reinterpret_cast<u32x2*>(p + 8 * own_half) = u32x2{v[0], v[1]};
+    };
+    // fragment of RT f32x4 row-tile vectors -> hi plane (and lo plane at +EB1 in X3 mode)
+    auto put_split = [&](unsigned char* eb, int s, const f32x4 (&v)[RT]) {
+        u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int tt = 0; tt < RT; tt++) {
+            u32x2 ph, pl;
+            if (X3) split4(v[tt], ph, pl);
+            else ph = pack4(v[tt]);
+            hi[2 * tt] = ph[0]; hi[2 * tt + 1] = ph[1];
+            if (X3) { lo[2 * tt] = pl[0]; lo[2 * tt + 1] = pl[1]; }
+        }
+        put_own(eb, s, hi);
+        if (X3) put_own(eb + EB1, s, lo);
+    };
+    // one product a*b as 1 (bf16) or 3 (split bf16: hi*hi + hi*lo + lo*hi) MFMAs
+    auto mfma3 = [&](bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 c) {
+        c = mfma(ah, bh, c);
+        if (X3) { c = mfma(ah, bl, c); c = mfma(al, bh, c); }
+        return c;
     };
 
     {
@@ -717,9 +754,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                 in[1][s] = useB ? inA[0][s] : inA[1][s];
             }
             // =========================== forward ===========================
-            u32x2 sv[NW][RT][5];  // saved (h, a_x, a_y, a_z, a_lap) of the own neurons, layers 1..L-1
+            // saved (h, a_x, a_y, a_z, a_lap) of the own neurons, layers 1..L-1: bf16 pairs, or
+            // fp32 in split-bf16 mode (the adjoint algebra must not be the precision bottleneck)
+            u32x2 sv[X3 ? 1 : NW][RT][5];
+            f32x4 svf[X3 ? NW : 1][RT][5];
+            f32x4 h0[RT];   // layer-0 activation of the own neurons (its reverse pass needs it)
             {   // ---- layer 0 on the VALU (K = 2), own neurons only
-                u32x4 xo[5];
+                f32x4 o[5][RT];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
                     const int n0 = 16 * (RT * part + tt) + 4 * g;
@@ -734,15 +775,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                     f32x4 s0, s1, s2;
                     act012v<ACT>(a[0], s0, s1, s2);
                     const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
-                    f32x4 o[5] = {s0, s1 * a[1], s1 * a[2], s1 * a[3], s1 * a[4] + s2 * q};
-#pragma unroll
-                    for (int s = 0; s < 5; s++) {
-                        const u32x2 p = pack4(o[s]);
-                        xo[s][2 * tt] = p[0]; xo[s][2 * tt + 1] = p[1];
-                    }
+                    o[0][tt] = s0;
+                    o[1][tt] = s1 * a[1];
+                    o[2][tt] = s1 * a[2];
+                    o[3][tt] = s1 * a[3];
+                    o[4][tt] = s1 * a[4] + s2 * q;
+                    h0[tt] = X3 ? s0 : unpack4(pack4(s0));   // bf16 mode: what the next layer saw
                 }
 #pragma unroll
-                for (int s = 0; s < 5; s++) put_own(XB, s, xo[s]);
+                for (int s = 0; s < 5; s++) put_split(XB, s, o[s]);
             }
             __syncthreads();
             float Sv = 0.f, Sl = 0.f;
@@ -759,34 +800,44 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                 }
 #pragma unroll
                 for (int kc = 0; kc < KC; kc++) {
-                    bf16x8 wa[RT];
+                    bf16x8 wa[RT], wl[RT];
 #pragma unroll
-                    for (int tt = 0; tt < RT; tt++)
-                        wa[tt] = *reinterpret_cast<const bf16x8*>(wf + (((RT * part + tt) * KC + kc) * 64 + lane) * 8);
+                    for (int tt = 0; tt < RT; tt++) {
+                        const __bf16* pw = wf + (((RT * part + tt) * KC + kc) * 64 + lane) * 8;
+                        wa[tt] = *reinterpret_cast<const bf16x8*>(pw);
+                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(pw + WPLANE) : wa[tt];
+                    }
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
-                        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xin + ((size_t)(kc * 5 + s) * 64 + lane) * 16);
+                        const unsigned char* px = xin + ((size_t)(kc * 5 + s) * 64 + lane) * 16;
+                        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(px);
+                        const bf16x8 xl = X3 ? *reinterpret_cast<const bf16x8*>(px + EB1) : xb;
 #pragma unroll
-                        for (int tt = 0; tt < RT; tt++) a[tt][s] = mfma(wa[tt], xb, a[tt][s]);
+                        for (int tt = 0; tt < RT; tt++) a[tt][s] = mfma3(wa[tt], wl[tt], xb, xl, a[tt][s]);
                     }
                 }
-                u32x4 xo[5];
+                f32x4 o[5][RT];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
                     f32x4 s0, s1, s2;
                     act012v<ACT>(a[tt][0], s0, s1, s2);
                     const f32x4 q = a[tt][1] * a[tt][1] + a[tt][2] * a[tt][2] + a[tt][3] * a[tt][3];
                     const f32x4 ol = s1 * a[tt][4] + s2 * q;
-                    sv[l - 1][tt][0] = pack4(s0);
+                    if (X3) {
+                        svf[l - 1][tt][0] = s0;
 #pragma unroll
-                    for (int s = 1; s < 5; s++) sv[l - 1][tt][s] = pack4(a[tt][s]);
+                        for (int s = 1; s < 5; s++) svf[l - 1][tt][s] = a[tt][s];
+                    } else {
+                        sv[l - 1][tt][0] = pack4(s0);
+#pragma unroll
+                        for (int s = 1; s < 5; s++) sv[l - 1][tt][s] = pack4(a[tt][s]);
+                    }
                     if (l < L - 1) {
-                        f32x4 o[5] = {s0, s1 * a[tt][1], s1 * a[tt][2], s1 * a[tt][3], ol};
-#pragma unroll
-                        for (int s = 0; s < 5; s++) {
-                            const u32x2 p = pack4(o[s]);
-                            xo[s][2 * tt] = p[0]; xo[s][2 * tt + 1] = p[1];
-                        }
+                        o[0][tt] = s0;
+                        o[1][tt] = s1 * a[tt][1];
+                        o[2][tt] = s1 * a[tt][2];
+                        o[3][tt] = s1 * a[tt][3];
+                        o[4][tt] = ol;
                     } else {
                         const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 16 * (RT * part + tt) + 4 * g);
                         const f32x4 pv = wo * s0, pl = wo * ol;
@@ -797,7 +848,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                 if (l < L - 1) {
                     unsigned char* xout = XB + (size_t)l * C::EB;
 #pragma unroll
-                    for (int s = 0; s < 5; s++) put_own(xout, s, xo[s]);
+                    for (int s = 0; s < 5; s++) put_split(xout, s, o[s]);
                     __syncthreads();
                 }
             }
@@ -836,13 +887,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
             const float pw = useB ? A.P : 1.0f;
             const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
             {   // ---- last hidden layer, own neurons
-                u32x4 yo[5];
+                f32x4 yo[5][RT];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
-                    const f32x4 h = unpack4(sv[NW - 1][tt][0]);
-                    f32x4 a[5];
+                    f32x4 h, a[5];
+                    if (X3) {
+                        h = svf[NW - 1][tt][0];
 #pragma unroll
-                    for (int s = 1; s < 5; s++) a[s] = unpack4(sv[NW - 1][tt][s]);
+                        for (int s = 1; s < 5; s++) a[s] = svf[NW - 1][tt][s];
+                    } else {
+                        h = unpack4(sv[NW - 1][tt][0]);
+#pragma unroll
+                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[NW - 1][tt][s]);
+                    }
                     f32x4 s1, s2, s3;
                     act123v<ACT>(h, s1, s2, s3);
                     const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
@@ -850,21 +907,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                     woacc[tt] += cv * h + cl * (s1 * a[4] + s2 * q);
                     const f32x4 o0 = cv * wo, ol = cl * wo;
                     const f32x4 u = 2.0f * s2 * ol;
-                    f32x4 ab[5];
-                    ab[4] = s1 * ol;
-                    ab[1] = u * a[1];
-                    ab[2] = u * a[2];
-                    ab[3] = u * a[3];
-                    ab[0] = s1 * o0 + (s2 * a[4] + s3 * q) * ol;
-                    bacc[L - 1][tt] += ab[0];
-#pragma unroll
-                    for (int s = 0; s < 5; s++) {
-                        const u32x2 p = pack4(ab[s]);
-                        yo[s][2 * tt] = p[0]; yo[s][2 * tt + 1] = p[1];
-                    }
+                    yo[4][tt] = s1 * ol;
+                    yo[1][tt] = u * a[1];
+                    yo[2][tt] = u * a[2];
+                    yo[3][tt] = u * a[3];
+                    yo[0][tt] = s1 * o0 + (s2 * a[4] + s3 * q) * ol;
+                    bacc[L - 1][tt] += yo[0][tt];
                 }
 #pragma unroll
-                for (int s = 0; s < 5; s++) put_own(YB, s, yo[s]);
+                for (int s = 0; s < 5; s++) put_split(YB, s, yo[s]);
             }
             __syncthreads();
 #pragma unroll
@@ -875,41 +926,38 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
 #pragma unroll
                 for (int ph = 0; ph < 3; ph++) {
                     // rows k = 8g + 4hh + (c>>2) of the phase: stream 2ph + (k>>4), point k&15
-                    const unsigned char* ay[2];
-                    const unsigned char* ax[2];
+                    size_t rowoff[2];
+                    bool pad[2];
 #pragma unroll
                     for (int hh = 0; hh < 2; hh++) {
                         const int k = 8 * g + 4 * hh + (c >> 2);
                         const int s = 2 * ph + (k >> 4), cc = k & 15;
-                        const bool pad = s > 4;  // phase 2, upper 16 rows: zeros
-                        const size_t rowoff = ((size_t)(s > 4 ? 0 : s) * 64 + cc) * 16 + (c & 1) * 8;
-                        ay[hh] = pad ? zero : YB + rowoff;   // + (kc*5*64 + gsel*16)*16 per tile below
-                        ax[hh] = pad ? zero : xin + rowoff;
+                        pad[hh] = s > 4;  // phase 2, upper 16 rows: zeros
+                        rowoff[hh] = ((size_t)(s > 4 ? 0 : s) * 64 + cc) * 16 + (c & 1) * 8;
                     }
                     const size_t chunk = (size_t)((c & 3) >> 1) * 16 * 16;  // slot group within the tile
-                    bf16x8 fx[HT];
-#pragma unroll
-                    for (int it = 0; it < HT; it++) {
-                        const size_t toff = ((size_t)(it >> 1) * 5 * 64 + (size_t)(2 * (it & 1)) * 16) * 16 + chunk;
-                        const bool z0 = ax[0] == zero, z1 = ax[1] == zero;
+                    auto frag = [&](const unsigned char* base, int T, int plane) {
+                        const size_t toff = ((size_t)(T >> 1) * 5 * 64 + (size_t)(2 * (T & 1)) * 16) * 16 + chunk +
+                                            (size_t)plane * EB1;
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(z0 ? zero : ax[0] + toff));
+                            (__attribute__((address_space(3))) bf16x4*)(pad[0] ? zero : base + rowoff[0] + toff));
                         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(z1 ? zero : ax[1] + toff));
-                        fx[it] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    }
+                            (__attribute__((address_space(3))) bf16x4*)(pad[1] ? zero : base + rowoff[1] + toff));
+                        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    };
+                    bf16x8 fy[RT], fyl[RT];
 #pragma unroll
                     for (int tt = 0; tt < RT; tt++) {
-                        const int T = RT * part + tt;
-                        const size_t toff = ((size_t)(T >> 1) * 5 * 64 + (size_t)(2 * (T & 1)) * 16) * 16 + chunk;
-                        const bool z0 = ay[0] == zero, z1 = ay[1] == zero;
-                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(z0 ? zero : ay[0] + toff));
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(z1 ? zero : ay[1] + toff));
-                        const bf16x8 fy = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        fy[tt] = frag(YB, RT * part + tt, 0);
+                        fyl[tt] = X3 ? frag(YB, RT * part + tt, 1) : fy[tt];
+                    }
 #pragma unroll
-                        for (int it = 0; it < HT; it++) wacc[l - 1][tt][it] = mfma(fy, fx[it], wacc[l - 1][tt][it]);
+                    for (int it = 0; it < HT; it++) {
+                        const bf16x8 fx = frag(xin, it, 0);
+                        const bf16x8 fxl = X3 ? frag(xin, it, 1) : fx;
+#pragma unroll
+                        for (int tt = 0; tt < RT; tt++)
+                            wacc[l - 1][tt][it] = mfma3(fy[tt], fyl[tt], fx, fxl, wacc[l - 1][tt][it]);
                     }
                 }
                 // ---- adjoint of layer l's input for the own neurons, then layer l-1's activation adjoint
@@ -921,18 +969,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                     for (int s = 0; s < 5; s++) ob[tt][s] = splat(0.f);
 #pragma unroll
                 for (int kc = 0; kc < KC; kc++) {
-                    bf16x8 wa[RT];
+                    bf16x8 wa[RT], wl[RT];
 #pragma unroll
-                    for (int tt = 0; tt < RT; tt++)
-                        wa[tt] = *reinterpret_cast<const bf16x8*>(wb + (((RT * part + tt) * KC + kc) * 64 + lane) * 8);
+                    for (int tt = 0; tt < RT; tt++) {
+                        const __bf16* pwb = wb + (((RT * part + tt) * KC + kc) * 64 + lane) * 8;
+                        wa[tt] = *reinterpret_cast<const bf16x8*>(pwb);
+                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(pwb + WPLANE) : wa[tt];
+                    }
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
-                        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(YB + ((size_t)(kc * 5 + s) * 64 + lane) * 16);
+                        const unsigned char* py = YB + ((size_t)(kc * 5 + s) * 64 + lane) * 16;
+                        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(py);
+                        const bf16x8 yl = X3 ? *reinterpret_cast<const bf16x8*>(py + EB1) : yb;
 #pragma unroll
-                        for (int tt = 0; tt < RT; tt++) ob[tt][s] = mfma(wa[tt], yb, ob[tt][s]);
+                        for (int tt = 0; tt < RT; tt++) ob[tt][s] = mfma3(wa[tt], wl[tt], yb, yl, ob[tt][s]);
                     }
                 }
-                u32x4 yo[5];
+                f32x4 yo[5][RT];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
                     f32x4 h, a[5];
@@ -943,9 +996,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                         const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
 #pragma unroll
                         for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
-                        const int Tn = RT * part + tt;
-                        const u32x4 hx = *reinterpret_cast<const u32x4*>(XB + ((size_t)((Tn >> 1) * 5 + 0) * 64 + lane) * 16);
-                        h = unpack4((Tn & 1) ? u32x2{hx[2], hx[3]} : u32x2{hx[0], hx[1]});
+                        h = h0[tt];
+                    } else if (X3) {
+                        h = svf[l - 2][tt][0];
+#pragma unroll
+                        for (int s = 1; s < 5; s++) a[s] = svf[l - 2][tt][s];
                     } else {
                         h = unpack4(sv[l - 2][tt][0]);
 #pragma unroll
@@ -971,16 +1026,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                         w0acc[tt][1] += g1;
                     } else {
 #pragma unroll
-                        for (int s = 0; s < 5; s++) {
-                            const u32x2 p = pack4(ab[s]);
-                            yo[s][2 * tt] = p[0]; yo[s][2 * tt + 1] = p[1];
-                        }
+                        for (int s = 0; s < 5; s++) yo[s][tt] = ab[s];
                     }
                 }
                 if (l - 1 >= 1) {   // hand the next layer's adjoints to the group
                     __syncthreads();   // everyone is done reading YB
 #pragma unroll
-                    for (int s = 0; s < 5; s++) put_own(YB, s, yo[s]);
+                    for (int s = 0; s < 5; s++) put_split(YB, s, yo[s]);
                     __syncthreads();
                 }
             }
@@ -1100,16 +1152,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
     if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
 }
 
-template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES>
+template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES, bool X3>
 hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
 {
     using C1 = MCfg<H, L>;
-    using C = M2Cfg<H, L, SPLIT, WAVES>;
+    using C = M2Cfg<H, L, SPLIT, WAVES, X3>;
     const int nfrag = C1::NW * 2 * C1::HT * C1::KC * 64;
-    hipLaunchKernelGGL((k_pack_weights<H, L>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
+    hipLaunchKernelGGL((k_pack_weights<H, L, X3>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    auto kern = k_trunk_mfma2<H, L, ACT, NPASS, MODE, SPLIT, WAVES>;
+    auto kern = k_trunk_mfma2<H, L, ACT, NPASS, MODE, SPLIT, WAVES, X3>;
     size_t lds = C::LDS_BYTES;
     const size_t need = C::GROUPS == 1 ? 64 : (size_t)(TrunkLayout<H, L>::size + 16) * 4;
     if (lds < need) lds = need;
@@ -1123,13 +1175,13 @@ hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int gr
     return hipGetLastError();
 }
 
-template <int H, int L, int SPLIT, int WAVES>
+template <int H, int L, int SPLIT, int WAVES, bool X3 = false>
 bool launch2_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, const TrunkArgs& A,
                 int grid, hipStream_t st, hipError_t* e)
 {
 #define PINN_MCASE2(ACT, NP, MD)                                                        \
     if (act == ACT && npass == NP && mode == MD) {                                      \
-        *e = launch2_t<H, L, ACT, NP, MD, SPLIT, WAVES>(theta, wpk, A, grid, st);        \
+        *e = launch2_t<H, L, ACT, NP, MD, SPLIT, WAVES, X3>(theta, wpk, A, grid, st);        \
         return true;                                                                    \
     }
     PINN_MCASE2(ACT_SIGMOID, 2, MODE_FWD) PINN_MCASE2(ACT_SIGMOID, 2, MODE_BWD)
@@ -1182,6 +1234,7 @@ bool launch_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, co
 }  // namespace
 
 bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
+bool mfma_x3_supported(int H, int L) { return (H == 64 || H == 128) && L == 2; }
 
 // A/B switch for measurements (see launch_trunk_mfma): PINN_MFMA_GEN = 1 (default), 2, 3.
 static int mfma_generation()
@@ -1194,15 +1247,20 @@ static int mfma_generation()
     return gen;
 }
 
-size_t mfma_packed_weight_bytes(int H, int L) { return (size_t)(L - 1) * 2 * H * H * 2; }
+size_t mfma_packed_weight_bytes(int H, int L) { return (size_t)2 * (L - 1) * 2 * H * H * 2; }  // hi + lo planes
 
 int mfma_partial_stride(int H, int L) { return 3 * H + (L - 1) * (H * H + H) + H + 1 + 3; }
 
-bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, const float* theta,
+bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, const float* theta,
                        void* packed_weights, const TrunkArgs& A, int grid, hipStream_t st,
                        hipError_t* err)
 {
     __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
+    if (x3) {   // split-bf16 operands (3 MFMAs per product): neuron-split kernel only
+        if (H == 64 && L == 2) return launch2_HL<64, 2, 4, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
+        if (H == 128 && L == 2) return launch2_HL<128, 2, 8, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
+        return false;
+    }
     // <H, L, SPLIT, WAVES>: SPLIT waves share a 16-point tile, WAVES per block.  Defaults are the
     // fastest measured decomposition per shape (1M points, MI355X, kernel ms):
     //   2x64 : point-split gen-1 0.90-0.95 | <2,8> 1.11 | <4,8> 0.97

@@ -455,3 +455,41 @@ def test_graph_replay_equals_eager_steps(golden_dir):
     assert int(a.step_count.item()) == int(b.step_count.item()) == 8
     assert torch.equal(a.theta, b.theta) and torch.equal(a.grad, b.grad)
     assert not torch.equal(xs[0], xs[1]) and not torch.equal(xs[3], xs[4])
+
+
+# ----------------------------------------------------------------------------- split-bf16 MFMA
+# PINN_PREC_BF16X3: every MFMA operand is hi + lo (two bf16), three MFMAs per product, fp32
+# accumulate, saved pre-activations kept in fp32.  16 operand mantissa bits instead of 8: this is
+# the wide path that meets the 1e-5 bar on psi (north_star) while still running on the bf16 pipe.
+@pytest.mark.parametrize("H,tag", [(64, "rand64"), (128, None)])
+def test_mfma_split_bf16_meets_the_fp32_bar(golden_dir, H, tag):
+    if tag:
+        g = np.load(os.path.join(golden_dir, "g2_formA_%s.npz" % tag))   # reference-generated
+        theta, x, y, z, R, mask = [g[k] for k in ("theta", "x", "y", "z", "R", "mask")]
+    else:
+        rng = np.random.default_rng(5)
+        A0 = O.arch(H=H)
+        off, sz = O.tensor_layout(A0)
+        fan = [2, 2, H, H, H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+        theta = np.zeros(O.param_count(A0))
+        for o, s, fi in zip(off, sz, fan):
+            theta[o:o + s] = rng.uniform(-1, 1, s) / np.sqrt(fi)
+        n = 2049
+        x, y, z = rng.uniform(-18, 18, (3, n))
+        R = rng.uniform(0.2, 4, n)
+        mask = ((np.sqrt((x - R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8)
+                + 2 * (np.sqrt((x + R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8))
+    A, Hm = O.arch(H=H), O.ham_A()
+    f = pkg.model.FORMULATION_A
+    arch = capi.Arch(H, 2, 32, 10, 0, 2, 1.0, capi.PINN_PREC_BF16X3)
+    h = capi.Handle(arch, 0, 4096)
+    fw = O.forward(A, Hm, theta, x, y, z, R)
+    ref = O.loss_grad(A, Hm, theta, x, y, z, R, mask)
+    psi, E, lap, res = run_forward(h, f, theta, x, y, z, R)
+    out = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    errs = dict(psi=rel(psi, fw["psi"]), lap=rel(lap, fw["lap"]), res=rel(res, fw["res"]),
+                loss=abs(out[h.P:].sum() / ref["Ltot"] - 1), grad=rel(out[:h.P], ref["grad"]))
+    print("mfma split-bf16 errors:", {k: "%.2e" % v for k, v in errs.items()})
+    assert errs["psi"] < 1e-5 and errs["lap"] < 1e-5 and errs["res"] < 5e-5
+    assert errs["loss"] < 2e-4 and errs["grad"] < 2e-4
+    assert np.array_equal(out, run_loss_grad(h, f, theta, x, y, z, R, mask))

@@ -59,13 +59,30 @@ ARCHS["wide4x128"] = dict(H=128, L=4, HE=32, HG=10, act=1, n_pass=2, out_scale=1
 ARCHS["wide64x3"] = dict(ARCHS["wide64"], precision="bf16x3", dtype="bf16x3",
                          label="2x64 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
                                "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
+ARCHS["wide128x3"] = dict(ARCHS["wide128"], precision="bf16x3", dtype="bf16x3",
+                          label="2x128 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
+                                "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
 DEFAULT_ARCH = "wide64"
+SECONDARY = {"wide64": ["wide64x3", "ref16", "wide128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
+             "wide128": ["wide128x3"], "wide128x3": ["wide128"]}
+# tolerances the GPU parity tests hold each path to, against the fp64 oracle / reference vectors
+# (tests/test_gpu_parity.py); "observed" = what those tests print on MI355X
+PARITY = {
+    "f32": "psi, E, lap 1e-5 rel; residual 2e-5; loss 1e-4; gradient 1e-4 (observed psi ~1e-7)",
+    "bf16": "psi 1e-2, lap 1e-2, residual 2e-2, loss 3e-2, gradient 3e-2 rel "
+            "(observed psi 1e-4..4e-3, gradient 2e-3..8e-3): bf16 operands cannot meet 1e-5",
+    "bf16x3": "psi, lap 1e-5 rel; residual 5e-5; loss, gradient 2e-4 (observed psi 2e-7..1e-6, "
+              "gradient 9e-7): split-bf16 operands, fp32 accumulate",
+}
 
 
-def cpu_baseline(theta_np, arch, budget_s=12.0):
-    """Reference formulation (nested autograd.grad, Adam) in PyTorch on the host cores."""
+def cpu_baseline(theta_np, arch, budget_s=15.0):
+    """Reference formulation (nested autograd.grad, Adam) in PyTorch on the host cores, on a
+    bounded sample of the same workload: the reference's own batch (100 000 points,
+    poc/main.py:39) for its architecture, 20 000 for the wide trunks (autograd through 64..128
+    wide layers is ~10x slower per point).  Hard wall-clock bounds everywhere."""
     from oracle import torch_baseline as TB
-    n = 100000                                   # the reference's own batch (poc/main.py:39)
+    n = 100000 if arch["H"] <= 16 else 20000
     ham = dict(a=-0.5, b=-1.0, c=-1.0, P=1.0)
     torch.manual_seed(12345)
     theta, step = TB.make_step(torch.tensor(theta_np), arch, ham, lr=8e-3, dtype=torch.float64)
@@ -74,28 +91,38 @@ def cpu_baseline(theta_np, arch, budget_s=12.0):
         x, y, z = [(torch.rand(n, dtype=torch.float64) * 36 - 18) for _ in range(3)]
         return x, y, z, torch.rand(n, dtype=torch.float64) * 3.8 + 0.2
 
-    step(*batch())                               # warm-up
-    # all cores is not the fastest setting for these small ops: try a few thread counts
-    # (one step each) and run the timed sample on the best one; its count is reported.
-    ncpu = os.cpu_count() or 1
-    best = (float("inf"), torch.get_num_threads())
-    for nt in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
-        torch.set_num_threads(nt)
-        step(*batch())
+    def timed_step():
         t1 = time.time()
         step(*batch())
-        best = min(best, (time.time() - t1, nt))
+        return time.time() - t1
+
+    t_all = time.time()
+    # all cores is not the fastest setting for these small ops: try a few thread counts (one
+    # warm-up + one timed step each, abandoned as soon as one is clearly slower or the search
+    # has used ~half the budget) and run the sample on the best; its count is what is reported.
+    ncpu = os.cpu_count() or 1
+    best = (float("inf"), min(8, ncpu))
+    for nt in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
+        torch.set_num_threads(nt)
+        timed_step()
+        dt1 = timed_step()
+        print("[cpu_baseline] %d threads: %.2f s/step (n=%d)" % (nt, dt1, n), file=sys.stderr, flush=True)
+        if dt1 < best[0]:
+            best = (dt1, nt)
+        if time.time() - t_all > budget_s / 2 or dt1 > 1.5 * best[0]:
+            break
     torch.set_num_threads(best[1])
     t0, k = time.time(), 0
-    while k < 3 or (time.time() - t0 < budget_s and k < 40):
-        step(*batch())
+    while k < 2 or (time.time() - t0 < budget_s and k < 40):
+        timed_step()
         k += 1
+        if time.time() - t_all > 3 * budget_s:
+            break
     dt = time.time() - t0
-    return {"value": n * k / dt, "unit": "points/s", "cores": torch.get_num_threads(),
-            "kind": "port",
+    return {"value": n * k / dt, "unit": "points/s", "cores": best[1], "kind": "port",
             "sample": "%d steps x %d points, fp64, PyTorch-CPU restatement of the reference "
                       "formulation (nested autograd.grad Laplacian + backward + Adam), "
-                      "%.1f s" % (k, n, dt)}
+                      "%.1f s on %d of %d host threads" % (k, n, dt, best[1], ncpu)}
 
 
 def main():
@@ -164,17 +191,22 @@ def main():
         return dt, kms, tr.losses()
 
     dt, trunk_ms, (Ltot, Lpde, Lbc) = run(model, args.arch)
-    # the other workload rides along as a secondary record (same K, W, points)
-    other = "ref16" if args.arch != "ref16" else "wide64"
-    oarch = ARCHS[other]
-    torch.manual_seed(12345)
-    omodel = pkg.NN_ion(params, oarch["H"], oarch["HE"], oarch["HG"], n_hidden=oarch["L"],
-                        act=oarch["act_name"], precision=oarch["precision"]).to(dev)
-    if other == "ref16":
-        omodel.load_flat_params(torch.tensor(
-            np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))["ionHsym"]))
-    odt, otrunk_ms, olosses = run(omodel, other)
-
+    # other workloads ride along as secondary records (same K, W, points): the split-bf16 variant
+    # of the primary (fp32-grade parity on the MFMA pipe), the reference architecture on the
+    # fp32 parity path, and the 2x128 trunk (highest matrix-pipe fraction)
+    others = [a for a in SECONDARY.get(args.arch, []) if a != args.arch]
+    sec = []
+    for other in others:
+        oarch = ARCHS[other]
+        torch.manual_seed(12345)
+        omodel = pkg.NN_ion(params, oarch["H"], oarch["HE"], oarch["HG"], n_hidden=oarch["L"],
+                            act=oarch["act_name"], precision=oarch["precision"]).to(dev)
+        if other == "ref16":
+            omodel.load_flat_params(torch.tensor(
+                np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))["ionHsym"]))
+        odt, otrunk_ms, olosses = run(omodel, other)
+        sec.append((other, oarch, odt, otrunk_ms, olosses))
+        del omodel
     if rank == 0:
         n_total = args.points * world
         fl_trunk = trunk_flops_per_point(arch["H"], arch["L"], arch["n_pass"])
@@ -206,15 +238,19 @@ def main():
                                   "bf16 dense MFMA peak; algorithmic trunk flops only")},
             "loss": {"Ltot": Ltot, "Lpde": Lpde, "Lbc": Lbc},
         }
-        ofl = trunk_flops_per_point(oarch["H"], oarch["L"], oarch["n_pass"])
-        oach = ofl * args.points / (otrunk_ms * 1e-3) / 1e12
-        out["secondary"] = {"workload": oarch["label"], "arch": other, "dtype": oarch["dtype"],
-                            "value": n_total * args.steps / odt, "unit": "points/s",
-                            "ms_per_step": odt / args.steps * 1e3,
-                            "roofline": {"bound": "mfma", "achieved": oach, "peak": oarch["peak"],
-                                         "unit": "TFLOP/s", "frac": oach / oarch["peak"],
-                                         "kernel_ms": otrunk_ms, "flops_per_point": ofl},
-                            "loss": {"Ltot": olosses[0]}}
+        out["parity"] = PARITY[arch["precision"]]
+        out["secondary"] = []
+        for other, oarch, odt, otrunk_ms, olosses in sec:
+            ofl = trunk_flops_per_point(oarch["H"], oarch["L"], oarch["n_pass"])
+            oach = ofl * args.points / (otrunk_ms * 1e-3) / 1e12
+            out["secondary"].append({
+                "workload": oarch["label"], "arch": other, "dtype": oarch["dtype"],
+                "value": n_total * args.steps / odt, "unit": "points/s",
+                "ms_per_step": odt / args.steps * 1e3,
+                "roofline": {"bound": "mfma", "achieved": oach, "peak": oarch["peak"],
+                             "unit": "TFLOP/s", "frac": oach / oarch["peak"],
+                             "kernel_ms": otrunk_ms, "flops_per_point": ofl},
+                "parity": PARITY[oarch["precision"]], "loss": {"Ltot": olosses[0]}})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(theta0, arch)
         print(json.dumps(out))

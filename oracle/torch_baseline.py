@@ -76,6 +76,6 @@ def make_step(theta0, arch, ham, lr=8e-3, dtype=torch.float64):
         Ltot = loss_terms(theta, arch, ham, x, y, z, R, i1, i2)[0]
         Ltot.backward()
         opt.step()
-        return float(Ltot)
+        return float(Ltot.detach())
 
     return theta, step

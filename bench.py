@@ -62,6 +62,9 @@ ARCHS["wide64x3"] = dict(ARCHS["wide64"], precision="bf16x3", dtype="bf16x3",
 ARCHS["wide128x3"] = dict(ARCHS["wide128"], precision="bf16x3", dtype="bf16x3",
                           label="2x128 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
                                 "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
+# HBM bytes per launch of each workload's trunk kernel from rocprofv3 PMC passes (FETCH_SIZE x 2 --
+# the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r01z_final_default_bench.md)
+TRAFFIC = {"wide64": 38.3e6, "wide64x3": 40.1e6, "ref16": 33.2e6, "wide128": 80.3e6}
 DEFAULT_ARCH = "wide64"
 SECONDARY = {"wide64": ["wide64x3", "ref16", "wide128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
              "wide128": ["wide128x3"], "wide128x3": ["wide128"]}
@@ -231,7 +234,8 @@ def main():
                        "points_per_gpu": args.points, "global_batch": n_total,
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None, "kernel": "k_trunk" if arch["dtype"] == "f32" else "k_trunk_mfma",
+                         "frac": achieved / peak, "traffic": TRAFFIC.get(args.arch),
+                         "traffic_source": "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r01z", "kernel": "k_trunk" if arch["dtype"] == "f32" else "k_trunk_mfma",
                          "kernel_ms": trunk_ms, "flops_per_point": fl_trunk,
                          "note": ("fp32 path: vector and f32-matrix peaks are both 157.3 TFLOP/s"
                                   if arch["dtype"] == "f32" else
@@ -248,7 +252,7 @@ def main():
                 "value": n_total * args.steps / odt, "unit": "points/s",
                 "ms_per_step": odt / args.steps * 1e3,
                 "roofline": {"bound": "mfma", "achieved": oach, "peak": oarch["peak"],
-                             "unit": "TFLOP/s", "frac": oach / oarch["peak"],
+                             "unit": "TFLOP/s", "frac": oach / oarch["peak"], "traffic": TRAFFIC.get(other),
                              "kernel_ms": otrunk_ms, "flops_per_point": ofl},
                 "parity": PARITY[oarch["precision"]], "loss": {"Ltot": olosses[0]}})
         if world == 1 and not args.no_cpu_baseline:

@@ -635,25 +635,34 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
     float* sbl = small + 3 * H;
     float* swo = small + 3 * H + NW * H;
     float* sbo = swo + H;
-    unsigned char* zero = lds_raw + C::OFF_ZERO;
+    // LDS addresses are 32-bit: every access below is (uniform base) + (one lane register) + immediate
+    typedef __attribute__((address_space(3))) unsigned char* lds_p;
+    const lds_p lds0 = (lds_p)lds_raw;
+    const lds_p zero = lds0 + C::OFF_ZERO;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave / SPLIT, part = wave % SPLIT;
     const int g = lane >> 4, c = lane & 15;
-    unsigned char* gbase = lds_raw + C::OFF_GRP + (size_t)grp * C::GBYTES;
-    unsigned char* XB = gbase;                          // [(L-1)] exchange buffers: outputs of layers 0..L-2
-    unsigned char* YB = gbase + (size_t)(L - 1) * C::EB; // adjoint exchange buffer
-    float* SB = reinterpret_cast<float*>(YB + C::EB);   // [SPLIT][16][2]
+    const lds_p gbase = lds0 + C::OFF_GRP + grp * C::GBYTES;
+    const lds_p XB = gbase;                             // [(L-1)] exchange buffers: outputs of layers 0..L-2
+    const lds_p YB = gbase + (L - 1) * C::EB;           // adjoint exchange buffer
+    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_GRP + (size_t)grp * C::GBYTES + (size_t)(L - 1) * C::EB + C::EB);   // [SPLIT][16][2]
+    const int lane16 = lane * 16;                       // lane-linear 16-byte fragment slot
+    // transposed-read lane offset: row (8g + 4hh + (c>>2)) -> stream half (g>>1), point 8(g&1)+(c>>2);
+    // 8-byte piece (c&1) of chunk ((c&3)>>1) of the tile: everything else is an immediate
+    const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
+    const bool padlane = g >= 2;                        // phase 2 has no sixth stream: those lanes read zeros
     // this wave's piece of B fragment (k-chunk, stream s): all 16 bytes (RT = 2) or one 8-byte half
     const int own_kc = (RT * part) >> 1, own_half = (RT * part) & 1;
-    auto put_own = [&](unsigned char* eb, int s, const u32x4& v) {
-        unsigned char* p = eb + ((size_t)(own_kc * 5 + s) * 64 + lane) * 16;
-        if (RT == 2) *reinterpret_cast<u32x4*>(p) = v;
-        else *reinterpret_cast<u32x2*>(p + 8 * own_half) = u32x2{v[0], v[1]};
+    const lds_p own_slot = (lds_p)(lds_p(0) + lane16 + own_kc * 5 * 64 * 16 + 8 * own_half);   // offset only
+    auto put_own = [&](lds_p eb, int s, const u32x4& v) {
+        const lds_p p = eb + (int)(size_t)own_slot + s * 64 * 16;
+        if (RT == 2) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(p) = v;
+        else *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(p) = u32x2{v[0], v[1]};
     };
     // fragment of RT f32x4 row-tile vectors -> hi plane (and lo plane at +EB1 in X3 mode)
-    auto put_split = [&](unsigned char* eb, int s, const f32x4 (&v)[RT]) {
+    auto put_split = [&](lds_p eb, int s, const f32x4 (&v)[RT]) {
         u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int tt = 0; tt < RT; tt++) {
@@ -687,7 +696,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
             for (int l = 1; l < L; l++) sbl[(l - 1) * H + k] = theta[Lay::b(l) + k];
         }
         if (threadIdx.x == 0) sbo[0] = theta[Lay::bout];
-        for (int k = threadIdx.x; k < C::ZBYTES / 4; k += NT) reinterpret_cast<unsigned*>(zero)[k] = 0u;
+        for (int k = threadIdx.x; k < C::ZBYTES / 4; k += NT)
+            reinterpret_cast<unsigned*>(lds_raw + C::OFF_ZERO)[k] = 0u;
     }
     __syncthreads();
     const __bf16* wsrc = C::WLDS ? wpk : wpk_g;   // one provenance per instantiation
@@ -790,7 +800,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
 #pragma unroll
             for (int l = 1; l < L; l++) {
                 const __bf16* wf = wsrc + (size_t)((l - 1) * 2 + 0) * H * H;
-                const unsigned char* xin = XB + (size_t)(l - 1) * C::EB;
+                const lds_p xin = XB + (l - 1) * C::EB + lane16;
                 f32x4 a[RT][5];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
@@ -809,9 +819,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                     }
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
-                        const unsigned char* px = xin + ((size_t)(kc * 5 + s) * 64 + lane) * 16;
-                        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(px);
-                        const bf16x8 xl = X3 ? *reinterpret_cast<const bf16x8*>(px + EB1) : xb;
+                        const lds_p px = xin + (kc * 5 + s) * 64 * 16;
+                        const bf16x8 xb = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(px);
+                        const bf16x8 xl = X3 ? *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(px + EB1) : xb;
 #pragma unroll
                         for (int tt = 0; tt < RT; tt++) a[tt][s] = mfma3(wa[tt], wl[tt], xb, xl, a[tt][s]);
                     }
@@ -846,7 +856,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                     }
                 }
                 if (l < L - 1) {
-                    unsigned char* xout = XB + (size_t)l * C::EB;
+                    const lds_p xout = XB + l * C::EB;
 #pragma unroll
                     for (int s = 0; s < 5; s++) put_split(xout, s, o[s]);
                     __syncthreads();
@@ -920,29 +930,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
             __syncthreads();
 #pragma unroll
             for (int l = L - 1; l >= 1; l--) {
-                const unsigned char* xin = XB + (size_t)(l - 1) * C::EB;
+                const lds_p xin = XB + (l - 1) * C::EB;
                 // ---- W_l-bar[own rows][all columns] += Y-bar (x) X, 32 of the 80 columns per phase,
                 //      both operands read transposed straight out of the exchange buffers
 #pragma unroll
                 for (int ph = 0; ph < 3; ph++) {
                     // rows k = 8g + 4hh + (c>>2) of the phase: stream 2ph + (k>>4), point k&15
-                    size_t rowoff[2];
-                    bool pad[2];
-#pragma unroll
-                    for (int hh = 0; hh < 2; hh++) {
-                        const int k = 8 * g + 4 * hh + (c >> 2);
-                        const int s = 2 * ph + (k >> 4), cc = k & 15;
-                        pad[hh] = s > 4;  // phase 2, upper 16 rows: zeros
-                        rowoff[hh] = ((size_t)(s > 4 ? 0 : s) * 64 + cc) * 16 + (c & 1) * 8;
-                    }
-                    const size_t chunk = (size_t)((c & 3) >> 1) * 16 * 16;  // slot group within the tile
-                    auto frag = [&](const unsigned char* base, int T, int plane) {
-                        const size_t toff = ((size_t)(T >> 1) * 5 * 64 + (size_t)(2 * (T & 1)) * 16) * 16 + chunk +
-                                            (size_t)plane * EB1;
-                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(pad[0] ? zero : base + rowoff[0] + toff));
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(pad[1] ? zero : base + rowoff[1] + toff));
+                    auto frag = [&](lds_p base, int T, int plane) {
+                        const int imm = ph * 2048 + (T >> 1) * 5 * 64 * 16 + (T & 1) * 512 + plane * EB1;
+                        const lds_p p0 = (ph == 2 && padlane) ? zero : base + trl + imm;
+                        const lds_p p1 = (ph == 2 && padlane) ? zero : base + trl + imm + 64;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
                         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     };
                     bf16x8 fy[RT], fyl[RT];
@@ -978,9 +977,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
                     }
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
-                        const unsigned char* py = YB + ((size_t)(kc * 5 + s) * 64 + lane) * 16;
-                        const bf16x8 yb = *reinterpret_cast<const bf16x8*>(py);
-                        const bf16x8 yl = X3 ? *reinterpret_cast<const bf16x8*>(py + EB1) : yb;
+                        const lds_p py = YB + lane16 + (kc * 5 + s) * 64 * 16;
+                        const bf16x8 yb = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(py);
+                        const bf16x8 yl = X3 ? *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(py + EB1) : yb;
 #pragma unroll
                         for (int tt = 0; tt < RT; tt++) ob[tt][s] = mfma3(wa[tt], wl[tt], yb, yl, ob[tt][s]);
                     }

@@ -131,8 +131,8 @@ def cpu_baseline(theta_np, arch, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--points", type=int, default=1000000, help="points per GPU per step")
     ap.add_argument("--arch", choices=sorted(ARCHS), default=DEFAULT_ARCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")

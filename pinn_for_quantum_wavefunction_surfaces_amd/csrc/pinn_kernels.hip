@@ -10,16 +10,16 @@
 //   k_reduce          fixed-order second-stage reduction of per-block partials (deterministic)
 //   k_adam        K4  Adam + best-so-far snapshot (train.py:23,58-60,72)
 //
-// Execution shape: one collocation point per lane (wave64).  Weights are read
-// with wave-uniform addresses, so hipcc places them in SGPRs (s_load through
-// the scalar cache) and every v_fmac takes its weight as a free scalar operand:
-// no LDS or VGPR is spent on the weights.  The only cross-lane work is the
-// weight-gradient contraction over points.  It is not done on the VALU: each
-// wave transposes (adjoint, input) vectors through a private LDS tile and
-// issues v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), accumulating 16x16
-// gradient tiles in registers for the whole kernel; the matrix pipe runs beside
-// the VALU, so the contraction is nearly free.  Per-block partials are written
-// once and summed in fixed order: results are bitwise reproducible.
+// Execution shape: one collocation point per lane (wave64).  Weights are read with wave-uniform
+// addresses, so hipcc keeps them in SGPRs (s_load through the scalar cache); every mat-vec is a
+// sequence of rank-1 updates on neuron PAIRS, v_pk_fma_f32 v[acc pair], s[weight pair], v[x]
+// (the fp32 vector peak is the packed rate), with the weight rows double-buffered in SGPRs.
+// The only cross-lane work is the weight-gradient contraction over points.  It is not done on the
+// VALU: each wave transposes (adjoint, input) vectors through a private LDS tile and issues
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains), accumulating 16x16 gradient tiles in registers
+// for the whole kernel; vector gradients are lane-local running sums reduced once at the end.
+// The R-net's 32x32 layer runs on v_mfma_f32_32x32x2_f32 with the matrix held in VGPRs.
+// Per-block partials are written once and summed in fixed order: results are bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -655,9 +655,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
     const bool padlane = g >= 2;                        // phase 2 has no sixth stream: those lanes read zeros
     // this wave's piece of B fragment (k-chunk, stream s): all 16 bytes (RT = 2) or one 8-byte half
     const int own_kc = (RT * part) >> 1, own_half = (RT * part) & 1;
-    const lds_p own_slot = (lds_p)(lds_p(0) + lane16 + own_kc * 5 * 64 * 16 + 8 * own_half);   // offset only
+    const int own_slot = lane16 + own_kc * 5 * 64 * 16 + 8 * own_half;   // byte offset of the own piece
     auto put_own = [&](lds_p eb, int s, const u32x4& v) {
-        const lds_p p = eb + (int)(size_t)own_slot + s * 64 * 16;
+        const lds_p p = eb + own_slot + s * 64 * 16;
         if (RT == 2) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(p) = v;
         else *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(p) = u32x2{v[0], v[1]};
     };

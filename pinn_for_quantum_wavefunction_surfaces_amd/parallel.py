@@ -2,11 +2,14 @@
 
 Points are i.i.d., the loss is a mean over points, so the path shards naturally:
 rank r draws points [r*n_local, (r+1)*n_local) of the global Philox stream and
-there are exactly two exchange steps per training step, both tiny SUM all-reduces:
-  * BC set sizes (int64[2]) after sampling, so every rank weights its boundary
+the only exchanged data are SUMs, of
+  * the BC set sizes (2 integers per batch), so every rank weights its boundary
     points with the GLOBAL 1/N_bc1, 1/N_bc2;
   * one flat fp32 buffer [grad(P) | Lpde, Lbc1, Lbc2] after the fused kernel
     (already scaled with global 1/N), after which every rank runs the same Adam.
+The Trainer sends both in ONE all-reduce per step: the next batch is sampled while
+the current step runs and its set sizes ride behind the gradient as two floats
+(exact below 2^24 points; above that, or for a one-off batch, reduce_counts is used).
 The backend is whatever torch.distributed was initialised with ("nccl" = RCCL over
 xGMI on MI355X; "gloo" in the CPU tests).  With world_size 1 nothing is called.
 """
@@ -47,6 +50,17 @@ class DataParallelPlan:
         """fp32[P+3] = [grad | three loss terms]: local partial -> global (in place)."""
         if self.collectives:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return buf
+
+    def reduce_grad_and_counts(self, buf, counts_local, counts_global):
+        """One message for both exchanges: buf = fp32[P+5] = [grad | three loss terms | 2 spare];
+        counts_local (int64[2], the NEXT batch's local BC set sizes) travel in the two spare
+        floats and come back summed in counts_global (int64[2]).  Needs n_global < 2^24."""
+        assert self.n_global < (1 << 24)
+        buf[-2:] = counts_local.to(torch.float32)
+        if self.collectives:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        counts_global.copy_(buf[-2:].round().to(torch.int64))
         return buf
 
     def max_over_ranks(self, seconds, device):

@@ -18,6 +18,15 @@ from .parallel import DataParallelPlan
 
 
 class Trainer:
+    """Owns the flat fp32 state (theta, Adam moments, point buffers) of one rank and runs steps.
+
+    Data parallel (plan.collectives): ONE small all-reduce per step.  The points of step t+1 are
+    sampled while step t is in flight (two point buffers), and their local boundary-set sizes
+    travel as two extra floats behind [grad | loss terms] of step t, so the global 1/N_bc of the
+    next step arrives with this step's gradient sum (exact: counts < 2^24).  Philox step t still
+    draws the points of training step t, so the point sequence does not depend on this pipelining.
+    """
+
     def __init__(self, model, params, n_points=None, lr=None, seed=12345, device=None,
                  plan=None, betas=(0.9, 0.999), eps=1e-8):
         self.model, self.params = model, params
@@ -35,32 +44,51 @@ class Trainer:
         self.theta = model.flat_params(dev).contiguous()
         self.m = torch.zeros(P, device=dev, dtype=f32)
         self.v = torch.zeros(P, device=dev, dtype=f32)
-        self.grad = torch.zeros(P + 3, device=dev, dtype=f32)
+        self.gbuf = torch.zeros(P + 5, device=dev, dtype=f32)   # [grad | Lpde Lbc1 Lbc2 | next counts]
+        self.grad = self.gbuf[:P + 3]
         self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
         self.best_theta = self.theta.clone()
         self.best_loss = torch.full((1,), float("inf"), device=dev, dtype=f32)
-        self.counts = torch.zeros(2, device=dev, dtype=torch.int64)
-        self.x, self.y, self.z, self.R = [torch.empty(self.n, device=dev, dtype=f32) for _ in range(4)]
-        self.mask = torch.empty(self.n, device=dev, dtype=torch.uint8)
+        self._pts = [[torch.empty(self.n, device=dev, dtype=f32) for _ in range(4)] +
+                     [torch.empty(self.n, device=dev, dtype=torch.uint8)] for _ in range(2)]
+        self._cnt = [torch.zeros(2, device=dev, dtype=torch.int64) for _ in range(2)]  # GLOBAL sizes
+        self._cnt_local = torch.zeros(2, device=dev, dtype=torch.int64)
+        self._cur = 0
         self.tmask = model.trainable_mask()
         self.t = 0
         self._sampled = False
+        # one-message pipelining needs exact float counts
+        self.pipelined = self.plan.collectives and self.plan.n_global < (1 << 24)
+
+    # the current batch (views change when the buffers swap)
+    x = property(lambda self: self._pts[self._cur][0])
+    y = property(lambda self: self._pts[self._cur][1])
+    z = property(lambda self: self._pts[self._cur][2])
+    R = property(lambda self: self._pts[self._cur][3])
+    mask = property(lambda self: self._pts[self._cur][4])
+    counts = property(lambda self: self._cnt[self._cur])
+
+    def _sample_into(self, buf, counts_out, step, ahead):
+        p = self.params
+        x, y, z, R, mask = self._pts[buf]
+        self.h.sample(self.seed, ahead if step is None else step, self.plan.first, self.n,
+                      float(p["xR"]), float(p["RxL"]), float(p["RxR"]), float(p["cutOff"]),
+                      float(p["BCcutoff"]), x, y, z, R, mask, counts_out,
+                      step_dev=self.step_count if step is None else None)
 
     def resample(self, step=None):
-        """Draw this rank's points of Philox step `step`; by default the step is the device-side
-        Adam step counter (so a captured graph of step() draws fresh points on every replay)."""
-        p = self.params
-        self.h.sample(self.seed, 0 if step is None else step, self.plan.first, self.n,
-                      float(p["xR"]), float(p["RxL"]), float(p["RxR"]), float(p["cutOff"]),
-                      float(p["BCcutoff"]), self.x, self.y, self.z, self.R, self.mask, self.counts,
-                      step_dev=self.step_count if step is None else None)
-        self.plan.reduce_counts(self.counts)
+        """Draw this rank's points of Philox step `step` into the current buffer and make their
+        global boundary-set sizes available; by default the step is the device-side Adam step
+        counter (so a captured graph of step() draws fresh points on every replay)."""
+        self._sample_into(self._cur, self._cnt[self._cur], step, 0)
+        self.plan.reduce_counts(self._cnt[self._cur])
         self._sampled = True
 
     def capture_graph(self, resample=True, track_best=True, warmup=3):
         """Capture one whole step (sample -> fused fwd+bwd -> all-reduce -> Adam) into a HIP graph
-        and return a callable that replays it: one host call per step instead of ~9, which is
-        what bounds the step time at the reference's own batch sizes (10^4..10^5 points)."""
+        and return a callable that replays it (bit-identical to eager steps).  Measured: no gain,
+        even at 10^4 points the step is bound by per-tile kernel latency, not by launches."""
+        self.pipelined = False                      # a graph is bound to one set of buffers
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -79,12 +107,21 @@ class Trainer:
 
     def step(self, resample=True, track_best=True):
         """One training step; returns nothing (read .losses() when a host value is wanted)."""
-        if resample or not self._sampled:
-            self.resample()
+        pipe = self.pipelined and resample
+        if not self._sampled or (resample and not self.pipelined):
+            self.resample()                         # non-pipelined: sample, then reduce the counts
+        cur = self._cur
+        x, y, z, R, mask = self._pts[cur]
         ham = self.model.ham(self.plan.invN, 0.0, 0.0)
-        self.h.residual_fwd_bwd(self.theta, self.x, self.y, self.z, self.R, self.mask, self.n, ham,
-                                self.counts, self.tmask, self.grad)
-        self.plan.reduce_grad(self.grad)
+        self.h.residual_fwd_bwd(self.theta, x, y, z, R, mask, self.n, ham, self._cnt[cur],
+                                self.tmask, self.grad)
+        if pipe:                                    # next step's points + their local counts
+            self._sample_into(1 - cur, self._cnt_local, None, 1)
+            # ONE message: [grad | losses | next counts]
+            self.plan.reduce_grad_and_counts(self.gbuf, self._cnt_local, self._cnt[1 - cur])
+            self._cur = 1 - cur
+        else:
+            self.plan.reduce_grad(self.grad)
         self.h.adam(self.theta, self.grad, self.m, self.v, self.step_count, self.lr, self.b1,
                     self.b2, self.eps, self.tmask,
                     self.best_theta if track_best else None,

@@ -457,6 +457,46 @@ def test_graph_replay_equals_eager_steps(golden_dir):
     assert not torch.equal(xs[0], xs[1]) and not torch.equal(xs[3], xs[4])
 
 
+def test_one_message_pipelined_step_equals_plain_step(golden_dir):
+    """data-parallel Trainer: next batch sampled one step ahead, its BC set sizes riding behind
+    the gradient in ONE all-reduce (RCCL, one rank here) -- same points, same theta, bit for bit,
+    as the plain sample -> reduce counts -> step -> reduce grad order"""
+    import torch.distributed as dist
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))["ionHsym"]
+    params = pkg.set_params()
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device(DEV))
+    try:
+        def make(force):
+            m = pkg.NN_ion(params).to(DEV)
+            m.load_flat_params(torch.tensor(w))
+            plan = pkg.DataParallelPlan(30000, rank=0, world=1, force_collectives=force)
+            return pkg.Trainer(m, params, n_points=30000, lr=8e-3, device=DEV, plan=plan)
+
+        a, b = make(False), make(True)
+        assert b.pipelined and not a.pipelined
+        b.resample()                                   # batch 0 (the steps then sample one ahead)
+        for i in range(6):
+            a.step()
+            xa, ca = a.x.clone(), a.counts.clone()     # the batch step i used
+            xb, cb = b.x.clone(), b.counts.clone()     # b: read BEFORE its step (buffers swap)
+            b.step()
+            assert torch.equal(xa, xb) and torch.equal(ca, cb), i
+            assert torch.equal(a.grad, b.grad), i
+        torch.cuda.synchronize()
+        assert torch.equal(a.theta, b.theta)
+        assert int(b.step_count.item()) == 6
+        b.step(resample=False)                         # frozen point set (end of train()): no swap
+        xb = b.x.clone()
+        b.step(resample=False)
+        assert torch.equal(xb, b.x) and int(b.step_count.item()) == 8
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 # ----------------------------------------------------------------------------- split-bf16 MFMA
 # PINN_PREC_BF16X3: every MFMA operand is hi + lo (two bf16), three MFMAs per product, fp32
 # accumulate, saved pre-activations kept in fp32.  16 operand mantissa bits instead of 8: this is

@@ -36,11 +36,20 @@ def _worker(rank, world, port, n_local, out_dir):
     buf = torch.tensor(np.concatenate([lg["grad"], [s[0] * plan.invN, s[1] / int(counts[0]),
                                                     s[2] / int(counts[1])]]))
     plan.reduce_grad(buf)
+    # the Trainer's one-message form: the next batch's local counts ride behind the gradient
+    lg32 = np.concatenate([lg["grad"], [s[0] * plan.invN, s[1] / int(counts[0]),
+                                        s[2] / int(counts[1])], [0, 0]]).astype(np.float32)
+    buf1 = torch.tensor(lg32)
+    nxt = O.sample(12345, 4, plan.first, n_local)[5]
+    nxt_global = torch.zeros(2, dtype=torch.int64)
+    plan.reduce_grad_and_counts(buf1, torch.tensor(nxt, dtype=torch.int64), nxt_global)
     tmax = plan.max_over_ranks(float(rank + 1), torch.device("cpu"))
     assert tmax == float(world)
     if rank == 0:
         np.save(os.path.join(out_dir, "dp.npy"), buf.numpy())
         np.save(os.path.join(out_dir, "counts.npy"), counts.numpy())
+        np.save(os.path.join(out_dir, "dp1.npy"), buf1.numpy())
+        np.save(os.path.join(out_dir, "counts_next.npy"), nxt_global.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,3 +72,7 @@ def test_two_shards_equal_one(tmp_path):
     P = ref["grad"].size
     assert np.abs(got[:P] - ref["grad"]).max() / np.abs(ref["grad"]).max() < 1e-12
     assert abs(got[P:].sum() / ref["Ltot"] - 1) < 1e-12
+    # one-message form: same sums (fp32 buffer), and the next batch's global set sizes exactly
+    got1 = np.load(tmp_path / "dp1.npy")
+    assert np.abs(got1[:P] - ref["grad"]).max() / np.abs(ref["grad"]).max() < 1e-6
+    assert tuple(np.load(tmp_path / "counts_next.npy")) == O.sample(12345, 4, 0, world * n_local)[5]

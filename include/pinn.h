@@ -105,6 +105,12 @@ int pinn_forward(pinn_handle *h, const float *theta, const float *x, const float
                  const float *z, const float *R, int64_t n, const pinn_ham *ham,
                  float *psi, float *E, float *lap, float *res, void *stream);
 
+/* E(R) with its first and second R-derivative (each n floats, any may be NULL).  Replaces
+ * the reference's autograd over the E-net for the force curves: F = -d(E + 1/(2R))/dR and
+ * dF/dR by grad(..., create_graph=True) twice (poc/main.py:249-253,1316-1328). */
+int pinn_energy_R(pinn_handle *h, const float *theta, const float *R, int64_t n, float *E,
+                  float *dE, float *d2E, void *stream);
+
 /* Replaces LossFunctions + Ltot.backward() (poc/main.py:341-355,403;
  * train.py:41-57,71): one fused pass computing the loss terms and d(Ltot)/d(theta).
  * out (P+3 floats): gradient, then invN*sum res^2, invN1*sum_{bc1} psi^2,

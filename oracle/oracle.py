@@ -47,6 +47,7 @@ def lib():
                                               C.POINTER(C.c_int64)]
         _lib.oracle_forward.argtypes = [C.POINTER(Arch), C.POINTER(Ham)] + [dp] * 5 + \
             [C.c_int64] + [dp] * 4
+        _lib.oracle_energy_R.argtypes = [C.POINTER(Arch), dp, dp, C.c_int64, dp, dp, dp]
         _lib.oracle_loss_grad.argtypes = [C.POINTER(Arch), C.POINTER(Ham)] + [dp] * 5 + \
             [C.POINTER(C.c_uint8), C.c_int64, C.c_double, C.c_double, C.c_double,
              C.c_uint64, dp, dp]
@@ -100,6 +101,14 @@ def forward(A, Hm, theta, x, y, z, R):
     lib().oracle_forward(C.byref(A), C.byref(Hm), _d(theta), _d(x), _d(y), _d(z), _d(R), n,
                          *[_d(o) for o in out])
     return dict(psi=out[0], E=out[1], lap=out[2], res=out[3])
+
+
+def energy_R(A, theta, R):
+    """E(R), dE/dR, d2E/dR2 of the E-net"""
+    theta, R = _pts(theta, R)
+    out = [np.empty(R.size) for _ in range(3)]
+    lib().oracle_energy_R(C.byref(A), _d(theta), _d(R), R.size, *[_d(o) for o in out])
+    return dict(E=out[0], dE=out[1], d2E=out[2])
 
 
 def loss_grad(A, Hm, theta, x, y, z, R, mask, invN=None, invN1=None, invN2=None,

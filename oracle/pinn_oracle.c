@@ -244,6 +244,40 @@ void oracle_forward(const oracle_arch *A, const oracle_ham *Hm, const double *th
     work_free(w);
 }
 
+/* E(R) with its first and second R-derivative: what the reference gets from
+ * grad([E],[R],create_graph=True) twice over Lin_E1/E2/Eout (poc/main.py:249-253,
+ * 1322-1328), written as three forward streams (value, d/dR, d2/dR2). */
+void oracle_energy_R(const oracle_arch *A, const double *theta, const double *R, int64_t n,
+                     double *E, double *dE, double *d2E)
+{
+    layout_t Lo;
+    make_layout(A, &Lo);
+    int HE = A->HE;
+    double *h = (double *)malloc(sizeof(double) * 3 * HE);
+    for (int64_t i = 0; i < n; i++) {
+        for (int k = 0; k < HE; k++) {
+            double w = theta[Lo.WE1 + k], s0, s1, s2, s3;
+            act4(A->act, w * R[i] + theta[Lo.bE1 + k], &s0, &s1, &s2, &s3);
+            h[k] = s0; h[HE + k] = s1 * w; h[2 * HE + k] = s2 * w * w;
+        }
+        double e = theta[Lo.bE3], de = 0.0, d2e = 0.0;
+        for (int j = 0; j < HE; j++) {
+            const double *W = theta + Lo.WE2 + (size_t)j * HE;
+            double a = theta[Lo.bE2 + j], da = 0.0, d2a = 0.0, s0, s1, s2, s3;
+            for (int k = 0; k < HE; k++) {
+                a += W[k] * h[k]; da += W[k] * h[HE + k]; d2a += W[k] * h[2 * HE + k];
+            }
+            act4(A->act, a, &s0, &s1, &s2, &s3);
+            double w3 = theta[Lo.WE3 + j];
+            e += w3 * s0; de += w3 * s1 * da; d2e += w3 * (s2 * da * da + s1 * d2a);
+        }
+        if (E) E[i] = e;
+        if (dE) dE[i] = de;
+        if (d2E) d2E[i] = d2e;
+    }
+    free(h);
+}
+
 /* ---------------------------------------------------------------- backward */
 
 /* reverse sweep through one trunk pass; ob[s][j] = adjoint of the last hidden

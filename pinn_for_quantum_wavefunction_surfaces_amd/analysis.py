@@ -65,6 +65,49 @@ def energy_from_psi_LCAO(Ri, params):
     return _integrate(ax, (psi * hpsi).reshape(shp)) / _integrate(ax, (psi * psi).reshape(shp))
 
 
+def dEdR_int(Ri, params, model):
+    """Hellmann-Feynman dE/dR at half-distance Ri (poc/main.py:639-676): <psi| dV/dR |psi> with
+    the normalised network psi on the n_test^3 grid, minus 1/(2 Ri^2); psi from the fused
+    forward kernel, dV/dR in closed form as in hamiltonian_R (poc/main.py:639-644)."""
+    n = int(params["n_test"])
+    dev = next(model.parameters()).device
+    ax, (x, y, z) = _grid(params, n, dev)
+    R = torch.full_like(x, float(Ri))
+    psi = model.evaluate(x, y, z, R, want=("psi",))["psi"].reshape(-1).double()
+    x, y, z = x.double(), y.double(), z.double()
+    r1 = torch.sqrt((x - Ri) ** 2 + y ** 2 + z ** 2)
+    r2 = torch.sqrt((x + Ri) ** 2 + y ** 2 + z ** 2)
+    VR = -(x - Ri) / r1.pow(3) + (x + Ri) / r2.pow(3)
+    shp = (n, n, n)
+    norm = _integrate(ax, (psi * psi).reshape(shp))
+    return _integrate(ax, (psi * VR * psi).reshape(shp)) / norm - 1 / (2 * Ri ** 2)
+
+
+def force_curves(model, R):
+    """-> (F, dF/dR) with F = -d(E_net + 1/(2R))/dR, the auto-diff force of
+    poc/main.py:1316-1328, through NN_ion.forward's R-differentiable E."""
+    R = R.detach().reshape(-1, 1).clone().requires_grad_(True)
+    zero = torch.zeros_like(R)
+    _, E = model(zero + 0.3, zero, zero, R)
+    ET = E + 1 / (2 * R)
+    ones = torch.ones_like(R)
+    F = -torch.autograd.grad([ET], [R], grad_outputs=ones, create_graph=True)[0]
+    F2 = torch.autograd.grad([F], [R], grad_outputs=ones)[0]
+    return F.detach(), F2.detach()
+
+
+def psi_cut(model, R0, n=1000, x_max=10.0):
+    """psi and the LCAO guess f1 + f2 along the x axis (y = z = 0) at half-distance R0: the
+    numbers behind plot.py:34-58 (its model.bin evaluation) and psiX_norm (poc/main.py:628-635)."""
+    dev = next(model.parameters()).device
+    x = torch.linspace(-x_max, x_max, n, dtype=torch.float64, device=dev)
+    zero = torch.zeros_like(x)
+    R = torch.full_like(x, float(R0))
+    psi = model.evaluate(x, zero, zero, R, want=("psi",))["psi"].reshape(-1)
+    lcao = torch.exp(-(x - R0).abs()) + torch.exp(-(x + R0).abs())
+    return x, psi, lcao
+
+
 def calculate_E_R(params, model=None):
     """E(R) table on R = RxL .. RxR step 0.1 (poc/main.py:495-517); returns the same dict."""
     if model is None:

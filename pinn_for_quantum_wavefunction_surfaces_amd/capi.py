@@ -14,7 +14,8 @@ PINN_PREC_F32, PINN_PREC_BF16, PINN_PREC_BF16X3 = 0, 1, 2
 
 EXPORTS = ["pinn_param_count", "pinn_tensor_count", "pinn_tensor_layout", "pinn_strerror",
            "pinn_create", "pinn_destroy", "pinn_last_error", "pinn_sample", "pinn_forward",
-           "pinn_residual_fwd_bwd", "pinn_adam", "pinn_profile_enable", "pinn_profile_read"]
+           "pinn_residual_fwd_bwd", "pinn_adam", "pinn_profile_enable", "pinn_profile_read",
+           "pinn_energy_R"]
 
 
 class PinnError(RuntimeError):
@@ -64,6 +65,7 @@ def load_library():
     lib.pinn_sample.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_int64, C.c_int64] + \
         [C.c_float] * 5 + [fp] * 4 + [vp, i64p, vp]
     lib.pinn_forward.argtypes = [vp] + [fp] * 5 + [C.c_int64, C.POINTER(Ham)] + [fp] * 4 + [vp]
+    lib.pinn_energy_R.argtypes = [vp, fp, fp, C.c_int64, fp, fp, fp, vp]
     lib.pinn_residual_fwd_bwd.argtypes = [vp] + [fp] * 5 + [vp, C.c_int64, C.POINTER(Ham), i64p,
                                                              C.c_uint64, fp, vp]
     lib.pinn_adam.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_double] * 4 + [C.c_uint64, fp, fp, vp]
@@ -146,6 +148,10 @@ class Handle:
         self._check(self.lib.pinn_forward(self.h, _ptr(theta), _ptr(x), _ptr(y), _ptr(z), _ptr(R),
                                           n, C.byref(ham), _ptr(psi), _ptr(E), _ptr(lap),
                                           _ptr(res), self._stream()), "pinn_forward")
+
+    def energy_R(self, theta, R, n, E=None, dE=None, d2E=None):
+        self._check(self.lib.pinn_energy_R(self.h, _ptr(theta), _ptr(R), n, _ptr(E), _ptr(dE),
+                                           _ptr(d2E), self._stream()), "pinn_energy_R")
 
     def residual_fwd_bwd(self, theta, x, y, z, R, mask, n, ham, bc_counts, trainable_mask, out):
         self._check(self.lib.pinn_residual_fwd_bwd(self.h, _ptr(theta), _ptr(x), _ptr(y), _ptr(z),

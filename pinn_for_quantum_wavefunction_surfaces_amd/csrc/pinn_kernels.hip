@@ -912,6 +912,54 @@ __global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t step0
 }  // namespace
 
 // =================================================================== C ABI
+// ------------------------------------------------------------------ E(R), dE/dR, d2E/dR2
+// The callers next to the hot path differentiate the E-net w.r.t. R with autograd (forces,
+// poc/main.py:1322-1328).  Three forward streams (value, d/dR, d2/dR2) through Lin_E1/E2/Eout;
+// one lane per R value, the layer-1 streams parked in a lane-private LDS column
+// (sh[(s*HE + k)*64 + lane]: bank = lane, conflict-free).  Tiny and rare: not tuned further.
+template <int ACT>
+__global__ __launch_bounds__(64) void k_energy_R(const float* __restrict__ thE, int HE,
+                                                 const float* __restrict__ R, int64_t n,
+                                                 float* __restrict__ E, float* __restrict__ dE,
+                                                 float* __restrict__ d2E)
+{
+    extern __shared__ float sh_e[];
+    const RnetLayout Lo{HE, 1};
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const float r = R[i < n ? i : n - 1];
+    for (int k = 0; k < HE; k++) {
+        const float w = thE[Lo.WE1() + k];
+        float s0, s1, s2;
+        act012<ACT>(w * r + thE[Lo.bE1() + k], s0, s1, s2);
+        sh_e[(0 * HE + k) * 64 + lane] = s0;
+        sh_e[(1 * HE + k) * 64 + lane] = s1 * w;
+        sh_e[(2 * HE + k) * 64 + lane] = s2 * w * w;
+    }
+    float e = thE[Lo.bE3()], de = 0.f, d2e = 0.f;
+    for (int j = 0; j < HE; j++) {
+        const float* W = thE + Lo.WE2() + j * HE;
+        float a = thE[Lo.bE2() + j], da = 0.f, d2a = 0.f;
+        for (int k = 0; k < HE; k++) {
+            const float w = W[k];
+            a += w * sh_e[(0 * HE + k) * 64 + lane];
+            da += w * sh_e[(1 * HE + k) * 64 + lane];
+            d2a += w * sh_e[(2 * HE + k) * 64 + lane];
+        }
+        float s0, s1, s2;
+        act012<ACT>(a, s0, s1, s2);
+        const float w3 = thE[Lo.WE3() + j];
+        e += w3 * s0;
+        de += w3 * s1 * da;
+        d2e += w3 * (s2 * da * da + s1 * d2a);
+    }
+    if (i < n) {
+        if (E) E[i] = e;
+        if (dE) dE[i] = de;
+        if (d2E) d2E[i] = d2e;
+    }
+}
+
 struct pinn_handle {
     pinn_arch arch;
     int device;
@@ -1240,6 +1288,26 @@ static int grid_for(int64_t n, int cap)
 {
     const int64_t tiles = (n + kBlock - 1) / kBlock;
     return (int)(tiles < cap ? tiles : cap);
+}
+
+extern "C" int pinn_energy_R(pinn_handle* h, const float* theta, const float* R, int64_t n,
+                             float* E, float* dE, float* d2E, void* stream)
+{
+    if (!h) return PINN_ERR_ARG;
+    if (!theta || !R) return fail(h, PINN_ERR_ARG, "null pointer argument");
+    if (n < 1) return fail(h, PINN_ERR_ARG, "n must be >= 1");
+    const pinn_arch& a = h->arch;
+    const size_t lds = (size_t)3 * a.HE * 64 * sizeof(float);
+    if (lds > 64 * 1024) return fail(h, PINN_ERR_UNSUPPORTED, "E-net wider than 85 neurons");
+    const dim3 grid((unsigned)((n + 63) / 64));
+    hipStream_t st = (hipStream_t)stream;
+    if (a.act == PINN_ACT_SIGMOID)
+        hipLaunchKernelGGL(k_energy_R<PINN_ACT_SIGMOID>, grid, dim3(64), lds, st, theta + h->PT, a.HE, R, n, E, dE, d2E);
+    else
+        hipLaunchKernelGGL(k_energy_R<PINN_ACT_TANH>, grid, dim3(64), lds, st, theta + h->PT, a.HE, R, n, E, dE, d2E);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_energy_R", e);
+    return PINN_OK;
 }
 
 extern "C" int pinn_forward(pinn_handle* h, const float* theta, const float* x, const float* y,

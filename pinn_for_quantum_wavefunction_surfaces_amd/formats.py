@@ -15,6 +15,10 @@ BIN_ORDER = [("Lin_H1", "H1"), ("Lin_H2", "H2"), ("Lin_out", "H3"), ("netDecayL"
              ("netDecay", "L2"), ("Lin_E1", "E1"), ("Lin_E2", "E2"), ("Lin_Eout", "E3")]
 
 
+# NN_ion registration order = state_dict key order (poc/main.py:234-245)
+STATE_ORDER = ["Lin_H1", "Lin_H2", "Lin_out", "Lin_E1", "Lin_E2", "Lin_Eout", "netDecayL", "netDecay"]
+
+
 def state_dict_to_bin_arrays(sd):
     """state_dict (tensors or arrays, L = 2) -> list of 16 float64 arrays in model.bin order."""
     out = []
@@ -56,6 +60,26 @@ def read_model_bin(path):
             n = int(np.prod(shape))
             arrs.append(np.frombuffer(f.read(n * 8), dtype="<f8").reshape(shape).copy())
     return arrs
+
+
+def pt_to_model_bin(pt_path, bin_path):
+    """NN_ion checkpoint (poc/main.py:331-339) -> model.bin for energy.py / plot.py."""
+    import torch
+    ck = torch.load(pt_path, map_location="cpu", weights_only=True)   # executes nothing
+    write_model_bin(bin_path, ck["model_state_dict"])
+
+
+def model_bin_to_pt(bin_path, pt_path, optimizer_state=None):
+    """model.bin -> checkpoint that NN_ion.loadModel reads (keys in registration order,
+    float64 like the reference's files)."""
+    import collections
+    import torch
+    sd = bin_arrays_to_state_dict(read_model_bin(bin_path))
+    osd = collections.OrderedDict()
+    for key in STATE_ORDER:
+        for suffix in (".weight", ".bias"):
+            osd[key + suffix] = torch.tensor(sd[key + suffix], dtype=torch.float64)
+    torch.save({"model_state_dict": osd, "optimizer_state_dict": optimizer_state or {}}, pt_path)
 
 
 def _np(t):

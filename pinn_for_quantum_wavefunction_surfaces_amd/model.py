@@ -103,6 +103,38 @@ class _FusedLoss(torch.autograd.Function):
         return (None,) * 6 + tuple(grads)
 
 
+class _EnergyOfR(torch.autograd.Function):
+    """E(R) of the E-net, differentiable twice w.r.t. R the way the reference's callers use it:
+    grad([E + 1/(2R)], [R], create_graph=True) for the force and once more for its slope
+    (poc/main.py:1316-1328).  Every level is one pinn_energy_R launch (value, d/dR, d2/dR2 as
+    three forward streams); nothing is differentiated numerically or on the host."""
+
+    @staticmethod
+    def forward(ctx, model, R):
+        ctx.model = model
+        ctx.save_for_backward(R)
+        return model.energy_R(R)[0]
+
+    @staticmethod
+    def backward(ctx, gE):
+        (R,) = ctx.saved_tensors
+        return None, gE * _dEdR.apply(ctx.model, R)
+
+
+class _dEdR(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, R):
+        _, dE, d2E = model.energy_R(R)
+        ctx.save_for_backward(d2E)
+        return dE
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (d2E,) = ctx.saved_tensors
+        return None, g * d2E
+
+
 class NN_ion(nn.Module):
     """Drop-in for poc/main.py:223-355.  `n_hidden`, `act`, `formulation` and `precision`
     are build extensions with the reference's values as defaults."""
@@ -205,9 +237,22 @@ class NN_ion(nn.Module):
         h.residual_fwd_bwd(theta, *xs, mask, n, ham, None, self.trainable_mask(), out)
         return out
 
+    def energy_R(self, R):
+        """(E, dE/dR, d2E/dR2), each shaped and typed like R, from one pinn_energy_R launch."""
+        n = R.numel()
+        h = self._handle_for(R.device, n)
+        out = [torch.empty(n, device=R.device, dtype=torch.float32) for _ in range(3)]
+        h.energy_R(self.flat_params(R.device), self._f32(R), n, *out)
+        return tuple(o.reshape(R.shape).to(R.dtype) for o in out)
+
     # ---- reference surface ------------------------------------------------------
     def forward(self, x, y, z, R):
-        """-> (Nout, E), each (n,1): poc/main.py:247-267."""
+        """-> (Nout, E), each (n,1): poc/main.py:247-267.  When R requires grad, E carries a
+        graph to R (twice differentiable: the force curves of poc/main.py:1316-1328); psi is
+        a plain value (the reference never differentiates it outside the loss)."""
+        if torch.is_grad_enabled() and R.requires_grad:
+            psi = self.evaluate(x, y, z, R, want=("psi",))["psi"]
+            return psi, _EnergyOfR.apply(self, R.reshape(-1, 1))
         o = self.evaluate(x, y, z, R, want=("psi", "E"))
         return o["psi"], o["E"]
 

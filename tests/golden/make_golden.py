@@ -19,6 +19,11 @@ What is produced:
                    + Wind-1965 table from poc/main.py:exactE
   g6_modelbin.npz  model.bin bytes written by train.py's serializer for the fine-tune
                    checkpoint + energy.py's e(R) evaluated from that file
+  g7_force.npz     callers next to the path: E(R), dE/dR, d2E/dR2 and the force curves by the
+                   reference's autograd statements (poc/main.py:1313-1332), the Hellmann-Feynman
+                   integral dEdR_int (poc/main.py:639-676), plot.py's psi cut from model.bin
+
+    python tests/golden/make_golden.py g7      # only the fixtures whose name starts with g7
 """
 import ast
 import hashlib
@@ -323,6 +328,60 @@ def gen_modelbin():
     print("g6_modelbin: %d bytes, e(R=0.2)=%.6f" % (len(blob), eR[0]))
 
 
+def gen_force(ns):
+    from torch.autograd import grad
+    NN_ion, params = ns["NN_ion"], ns["params"]
+    R = np.linspace(0.2, 4.0, 191)
+    out = dict(R=R)
+    for tag, ck in (("ionHsym", "ionHsym.pt"), ("fineTune", "ionHsym_fineTune.pt")):
+        model = NN_ion(params)
+        sd = torch.load(os.path.join(REF, "models", ck), map_location="cpu",
+                        weights_only=True)["model_state_dict"]
+        model.load_state_dict(sd)
+        Rt = as_col(R, True)
+        xt, yt, zt = as_col(0.3 + 0 * R, True), as_col(0 * R, True), as_col(0 * R, True)
+        _, E = model.parametricPsi(xt, yt, zt, Rt)
+        ones = torch.ones(Rt.shape, dtype=torch.float64)
+        ET = E + 1 / (2 * Rt)                                        # poc/main.py:1316
+        F = -grad([ET], [Rt], grad_outputs=ones, create_graph=True)[0]   # :1322-1324
+        F2 = grad([F], [Rt], grad_outputs=ones, create_graph=True)[0]    # :1326-1328
+        dE = grad([E], [Rt], grad_outputs=ones, create_graph=True)[0]
+        d2E = grad([dE], [Rt], grad_outputs=ones)[0]
+        d = lambda t: t.detach().numpy().ravel().copy()
+        out.update({tag + "_E": d(E), tag + "_dE": d(dE), tag + "_d2E": d(d2E),
+                    tag + "_F": d(F), tag + "_F2": d(F2)})
+    # Hellmann-Feynman integral on a 40^3 grid, the reference's function as is
+    p = dict(params)
+    p["n_test"] = 40
+    p["loadModelPath"] = os.path.join(REF, "models", "ionHsym.pt")
+    ns["params"] = p                       # poc/main.py functions read the module-level dict too
+    Ri = np.array([0.7, 1.0, 2.0])
+    out["hf_Ri"] = Ri
+    out["hf_n_test"] = 40
+    out["hf_dEdR"] = np.array([float(ns["dEdR_int"](float(r), p)) for r in Ri])
+    ns["params"] = params
+    # plot.py: psi along the x axis from model.bin (its statements, run in a scratch cwd)
+    blob = np.load(os.path.join(OUT, "g6_modelbin.npz"))["blob"].tobytes()
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            open("model.bin", "wb").write(blob)
+            os.environ["MPLBACKEND"] = "Agg"
+            np.product = np.prod
+            penv = {"__name__": "ref_plot"}
+            exec(compile(open(os.path.join(REF, "plot.py")).read(), "plot.py", "exec"), penv)
+            out["cut_R0"] = float(penv["R0"])           # the loop's last pass (R0 = 2)
+            out["cut_x"] = penv["x"][:, 0].copy()
+            out["cut_psi"] = penv["psi"][:, 0].copy()
+            out["cut_psi_lcao"] = penv["psi_lcao"][:, 0].copy()
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "g7_force.npz"), **out)
+    print("g7_force: F(R=2)=%.6f  HF dE/dR=%s  psi_cut(0)=%.6f" % (
+        out["ionHsym_F"][90], out["hf_dEdR"], out["cut_psi"][500]))
+
+
 def gen_weights():
     out = {}
     for tag, ck in (("ionHsym", "ionHsym.pt"), ("fineTune", "ionHsym_fineTune.pt")):
@@ -341,12 +400,13 @@ def main():
     torch.set_default_dtype(torch.float64)         # poc/main.py:915, train.py:77
     torch.set_num_threads(4)
     ns = load_main_defs()
-    gen_weights()
-    gen_form_A(ns)
-    gen_form_B()
-    gen_adam(ns)
-    gen_energy(ns)
-    gen_modelbin()
+    only = sys.argv[1] if len(sys.argv) > 1 else "g"
+    jobs = [("g1", gen_weights, ()), ("g2", gen_form_A, (ns,)), ("g3", gen_form_B, ()),
+            ("g4", gen_adam, (ns,)), ("g5", gen_energy, (ns,)), ("g6", gen_modelbin, ()),
+            ("g7", gen_force, (ns,))]
+    for name, fn, args in jobs:
+        if name.startswith(only):
+            fn(*args)
 
 
 if __name__ == "__main__":

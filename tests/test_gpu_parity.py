@@ -432,6 +432,57 @@ def test_energy_from_psi_matches_oracle_quadrature(golden_dir):
     assert abs(pkg.energy_from_psi_LCAO(1.0, params) - e["Elcao"][k]) < 5e-3
 
 
+@pytest.mark.parametrize("tag", ["ionHsym", "fineTune"])
+def test_energy_R_and_force_curves(golden_dir, tag):
+    """pinn_energy_R vs the reference's autograd over the E-net (g7, poc/main.py:1316-1328):
+    E, dE/dR, d2E/dR2 directly, and F, dF/dR through NN_ion.forward's R-differentiable E with
+    the reference's own grad(..., create_graph=True) call pattern.  fp32: 1e-5 of the curve's
+    scale (the second derivative passes through more cancellation: 5e-5)."""
+    g = np.load(os.path.join(golden_dir, "g7_force.npz"))
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))[tag]
+    model = pkg.NN_ion(pkg.set_params()).to(DEV)
+    model.load_flat_params(torch.tensor(w))
+    R = torch.tensor(g["R"], device=DEV, dtype=torch.float64).reshape(-1, 1)
+    E, dE, d2E = [t.cpu().numpy().ravel() for t in model.energy_R(R)]
+    for got, key, tol in ((E, "_E", 1e-5), (dE, "_dE", 1e-5), (d2E, "_d2E", 5e-5)):
+        ref = g[tag + key]
+        assert np.abs(got - ref).max() < tol * np.abs(ref).max(), key
+    F, F2 = pkg.force_curves(model, R)
+    assert np.abs(F.cpu().numpy().ravel() - g[tag + "_F"]).max() < 1e-5 * np.abs(g[tag + "_F"]).max()
+    assert np.abs(F2.cpu().numpy().ravel() - g[tag + "_F2"]).max() < 5e-5 * np.abs(g[tag + "_F2"]).max()
+    # tanh E-net of another width against the oracle (generic HE, second activation)
+    A = O.arch(H=16, HE=16, HG=8, act=1)
+    rng = np.random.default_rng(3)
+    th = rng.uniform(-0.7, 0.7, O.param_count(A))
+    m2 = pkg.NN_ion(pkg.set_params(), 16, 16, 8, act="tanh").to(DEV)
+    m2.load_flat_params(torch.tensor(th))
+    ref = O.energy_R(A, th, g["R"])
+    got = m2.energy_R(R)
+    for t, k in zip(got, ("E", "dE", "d2E")):
+        assert np.abs(t.cpu().numpy().ravel() - ref[k]).max() < 2e-5 * max(1.0, np.abs(ref[k]).max()), k
+
+
+def test_hellmann_feynman_and_psi_cut(golden_dir):
+    """the two remaining callers next to the path, against numbers produced by the reference's
+    own functions (make_golden.py g7): dEdR_int (poc/main.py:639-676) on a 40^3 grid and
+    plot.py's psi cut from model.bin (formulation B algebra)"""
+    g = np.load(os.path.join(golden_dir, "g7_force.npz"))
+    W = np.load(os.path.join(golden_dir, "g1_weights.npz"))
+    params = pkg.set_params()
+    params["n_test"] = int(g["hf_n_test"])
+    model = pkg.NN_ion(params).to(DEV)
+    model.load_flat_params(torch.tensor(W["ionHsym"]))
+    for Ri, ref in zip(g["hf_Ri"], g["hf_dEdR"]):
+        got = pkg.dEdR_int(float(Ri), params, model)
+        assert abs(got - ref) < 2e-5 * max(1.0, abs(ref)), (Ri, got, ref)
+    mB = pkg.NN_ion(params, formulation="B").to(DEV)
+    mB.load_flat_params(torch.tensor(W["fineTune"]))
+    x, psi, lcao = pkg.psi_cut(mB, float(g["cut_R0"]), n=g["cut_x"].size, x_max=10.0)
+    assert np.abs(x.cpu().numpy() - g["cut_x"]).max() < 1e-12
+    assert np.abs(psi.cpu().numpy() - g["cut_psi"]).max() < 1e-5 * np.abs(g["cut_psi"]).max()
+    assert np.abs(lcao.cpu().numpy() - g["cut_psi_lcao"]).max() < 1e-12
+
+
 def test_graph_replay_equals_eager_steps(golden_dir):
     """the whole step as one captured HIP graph: same trajectory as eager launches, bit for bit,
     and fresh points on every replay (the Philox step is read from the device-side counter)"""

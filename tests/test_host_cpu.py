@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "pinn.h")).read()
-    declared = set(re.findall(r"\b(pinn_[a-z_0-9]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(pinn_[A-Za-z_0-9]+)\s*\(", hdr))
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     lib = C.CDLL(capi.LIB_PATH)
     for name in declared:
@@ -104,6 +104,31 @@ def test_model_bin_is_byte_identical_to_reference_writer(tmp_path, golden_dir):
     R = g["R"][:, None]
     e = sig(sig(R @ E1a + E1b) @ E2a + E2b) @ E3a + E3b
     assert np.max(np.abs(e[:, 0] - g["e"])) < 1e-13
+
+
+def test_pt_and_model_bin_convert_both_ways(tmp_path, golden_dir):
+    """.pt -> model.bin gives the reference writer's bytes; model.bin -> .pt loads back into
+    NN_ion with the reference's key order and values"""
+    import collections
+    g = np.load(os.path.join(golden_dir, "g6_modelbin.npz"))
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))["fineTune"]
+    torch.set_default_dtype(torch.float64)          # the reference's files are fp64
+    try:
+        m = pkg.NN_ion(pkg.set_params())
+        m.load_flat_params(torch.tensor(w))
+        pt, binp, pt2 = [str(tmp_path / n) for n in ("a.pt", "model.bin", "b.pt")]
+        torch.save({"model_state_dict": collections.OrderedDict(m.state_dict()),
+                    "optimizer_state_dict": {}}, pt)
+        pkg.formats.pt_to_model_bin(pt, binp)
+        assert open(binp, "rb").read() == g["blob"].tobytes()
+        pkg.formats.model_bin_to_pt(binp, pt2)
+        sd = torch.load(pt2, map_location="cpu", weights_only=True)["model_state_dict"]
+        assert list(sd) == list(m.state_dict())
+        m2 = pkg.NN_ion(pkg.set_params())
+        m2.load_state_dict(sd)
+        assert torch.equal(m2.flat_params(dtype=torch.float64), torch.tensor(w))
+    finally:
+        torch.set_default_dtype(torch.float32)
 
 
 def test_no_cpu_fallback():

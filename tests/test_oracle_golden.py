@@ -102,6 +102,35 @@ def test_energy_py_curve_from_model_bin(golden_dir):
     assert np.max(np.abs(f["E"] - g["e"])) < 1e-13
 
 
+@pytest.mark.parametrize("tag", ["ionHsym", "fineTune"])
+def test_energy_R_derivatives_match_reference_autograd(golden_dir, tag):
+    """E(R), dE/dR, d2E/dR2 as three forward streams vs the reference's autograd statements
+    (poc/main.py:1316-1328, run by make_golden.py): value and both force curves"""
+    g = np.load(os.path.join(golden_dir, "g7_force.npz"))
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))[tag]
+    r = O.energy_R(O.arch(), w, g["R"])
+    for k in ("E", "dE", "d2E"):
+        ref = g[tag + "_" + k]
+        assert np.abs(r[k] - ref).max() < 1e-12 * np.abs(ref).max(), k
+    F = -(r["dE"] - 1 / (2 * g["R"] ** 2))
+    F2 = -(r["d2E"] + 1 / g["R"] ** 3)
+    assert np.abs(F - g[tag + "_F"]).max() < 1e-12 * np.abs(g[tag + "_F"]).max()
+    assert np.abs(F2 - g[tag + "_F2"]).max() < 1e-12 * np.abs(g[tag + "_F2"]).max()
+
+
+def test_psi_cut_of_plot_py(golden_dir):
+    """plot.py's psi along the x axis (its own evaluation of model.bin, formulation B algebra:
+    2*h, one pass) vs the oracle on the same weights"""
+    g = np.load(os.path.join(golden_dir, "g7_force.npz"))
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))["fineTune"]
+    x = g["cut_x"]
+    fw = O.forward(O.arch(n_pass=1, out_scale=2.0), O.ham_B(), w, x, 0 * x, 0 * x,
+                   np.full(x.size, float(g["cut_R0"])))
+    assert np.abs(fw["psi"] - g["cut_psi"]).max() < 1e-13
+    lcao = np.exp(-np.abs(x - g["cut_R0"])) + np.exp(-np.abs(x + g["cut_R0"]))
+    assert np.abs(lcao - g["cut_psi_lcao"]).max() < 1e-14
+
+
 def test_philox_known_answers():
     """Random123 kat_vectors for philox4x32-10."""
     assert O.philox([0] * 4, [0] * 2) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]

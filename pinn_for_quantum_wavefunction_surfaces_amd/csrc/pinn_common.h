@@ -26,7 +26,8 @@ struct TrunkArgs {
 // packed bf16 weights for one call: [(L-1)][2 (fwd, bwd)][H*H] (see pack order there)
 size_t mfma_packed_weight_bytes(int H, int L);
 bool mfma_trunk_supported(int H, int L);
-int mfma_partial_stride(int H, int L);   // floats per block partial row (trunk grads + 3)
+int mfma_partial_stride(int H, int L);
+int mfma_blocks_per_cu(int H, int L, bool x3);   // resident blocks per CU of the chosen kernel   // floats per block partial row (trunk grads + 3)
 // enqueue pack + trunk kernel; returns false when (H, L, act, npass, mode) has no instantiation
 bool mfma_x3_supported(int H, int L);
 bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, const float* theta,

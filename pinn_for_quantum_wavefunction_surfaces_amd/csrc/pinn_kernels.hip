@@ -1182,7 +1182,9 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const int64_t tiles = (max_points + kBlock - 1) / kBlock;
     // one resident 4-wave block per CU for both trunk kernels (1 wave per SIMD)
-    h->nbT = (int)(tiles < (int64_t)cus ? tiles : (int64_t)cus);
+    const int bpc = arch->precision != PINN_PREC_F32
+                        ? mfma_blocks_per_cu(arch->H, arch->L, arch->precision == PINN_PREC_BF16X3) : 1;
+    h->nbT = (int)(tiles < (int64_t)cus * bpc ? tiles : (int64_t)cus * bpc);
     h->nbR = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
     h->strideT = h->PT + 3;
     h->strideR = h->PR;

@@ -271,11 +271,14 @@ __global__ __launch_bounds__(kBlock, 1) void k_trunk_mfma(const float* __restric
         const float lapF = inA[0][4] + A.P * inA[1][4];
 
         Tail<float> t;
-        float SvA = 0.f, SlA = 0.f;
-        constexpr int nstage = NPASS == 2 ? (MODE == MODE_BWD ? 3 : 2) : 1;
-#pragma unroll 1
-        for (int st = 0; st < nstage; st++) {
-            const bool useB = NPASS == 2 && st == 1;
+        // saved forward state of every pass: the reverse sweeps (pass B first, then pass A) reuse
+        // it, so no pass is evaluated twice
+        u32x4 xbS[NPASS][L - 1][KC][5];   // B fragments of layer l's output streams (inputs of layer l+1)
+        u32x2 svS[NPASS][NW][HT][5];      // saved (h, a_x, a_y, a_z, a_lap) of layers 1..L-1 as bf16
+        float SvT = 0.f, SlT = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ps++) {
+            const bool useB = ps == 1;
             float in[2][5];
 #pragma unroll
             for (int s = 0; s < 5; s++) {
@@ -283,9 +286,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_trunk_mfma(const float* __restric
                 in[1][s] = useB ? inA[0][s] : inA[1][s];
             }
             // =========================== forward ===========================
-            // xb[l][kc][s]: B fragments of layer l's output streams (inputs of layer l+1)
-            u32x4 xb[L - 1][KC][5];
-            u32x2 sv[NW][HT][5];  // saved (h, a_x, a_y, a_z, a_lap) of layers 1..L-1 as bf16
+            u32x4 (&xb)[L - 1][KC][5] = xbS[ps];
+            u32x2 (&sv)[NW][HT][5] = svS[ps];
             // ---- layer 0 on the VALU (K = 2)
 #pragma unroll
             for (int jt = 0; jt < HT; jt++) {
@@ -350,30 +352,41 @@ __global__ __launch_bounds__(kBlock, 1) void k_trunk_mfma(const float* __restric
             }
             Sv = xg_sum(Sv);
             Sl = xg_sum(Sl);
-            const bool do_tail = NPASS == 1 || st == 1;
-            if (NPASS == 2 && st == 0) { SvA = Sv; SlA = Sl; }
-            if (do_tail) {
-                if (NPASS == 2) { Sv = SvA + A.P * Sv; Sl = SlA + A.P * Sl; }
-                const float N = A.out_scale * Sv + sbo[0];
-                const float lapN = A.out_scale * Sl;
-                tail<float>(N, lapN, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1, m2, A.invN, invN1,
-                            invN2, valid ? 1.0f : 0.0f, t);
-                if (MODE == MODE_FWD) {
-                    if (valid && g == 0) {
-                        if (A.psi) A.psi[idx] = t.psi;
-                        if (A.lap) A.lap[idx] = t.lap;
-                        if (A.res) A.res[idx] = t.res;
-                    }
-                } else {
-                    if (valid && g == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
-                    acc_pde += lead * t.l_pde;
-                    acc_bc1 += lead * t.l_bc1;
-                    acc_bc2 += lead * t.l_bc2;
-                    acc_bout += lead * t.Nb;
+            SvT += (useB ? A.P : 1.0f) * Sv;
+            SlT += (useB ? A.P : 1.0f) * Sl;
+        }
+        {
+            const float N = A.out_scale * SvT + sbo[0];
+            const float lapN = A.out_scale * SlT;
+            tail<float>(N, lapN, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1, m2, A.invN, invN1,
+                        invN2, valid ? 1.0f : 0.0f, t);
+            if (MODE == MODE_FWD) {
+                if (valid && g == 0) {
+                    if (A.psi) A.psi[idx] = t.psi;
+                    if (A.lap) A.lap[idx] = t.lap;
+                    if (A.res) A.res[idx] = t.res;
                 }
+            } else {
+                if (valid && g == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+                acc_pde += lead * t.l_pde;
+                acc_bc1 += lead * t.l_bc1;
+                acc_bc2 += lead * t.l_bc2;
+                acc_bout += lead * t.Nb;
             }
-            if (!(MODE == MODE_BWD && (NPASS == 1 || st >= 1))) continue;
-            // =========================== reverse ===========================
+        }
+        if (MODE != MODE_BWD) continue;
+        // =========================== reverse ===========================
+#pragma unroll
+        for (int ps = NPASS - 1; ps >= 0; ps--) {
+            const bool useB = ps == 1;
+            float in[2][5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                in[0][s] = useB ? inA[1][s] : inA[0][s];
+                in[1][s] = useB ? inA[0][s] : inA[1][s];
+            }
+            u32x4 (&xb)[L - 1][KC][5] = xbS[ps];
+            u32x2 (&sv)[NW][HT][5] = svS[ps];
             const float pw = useB ? A.P : 1.0f;
             const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
             u32x4 yb[KC][5];  // B fragments of the current layer's pre-activation adjoints
@@ -617,8 +630,8 @@ struct M2Cfg {
     static constexpr size_t LDS_BYTES = OFF_GRP + (size_t)GROUPS * GBYTES;
 };
 
-template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES, bool X3>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const float* __restrict__ theta,
+template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES, bool X3, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(const float* __restrict__ theta,
                                                                       const __bf16* __restrict__ wpk_g,
                                                                       TrunkArgs A)
 {
@@ -1151,7 +1164,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k_trunk_mfma2(const flo
     if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
 }
 
-template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES, bool X3>
+template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES, bool X3, int OCC>
 hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
 {
     using C1 = MCfg<H, L>;
@@ -1160,7 +1173,7 @@ hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int gr
     hipLaunchKernelGGL((k_pack_weights<H, L, X3>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    auto kern = k_trunk_mfma2<H, L, ACT, NPASS, MODE, SPLIT, WAVES, X3>;
+    auto kern = k_trunk_mfma2<H, L, ACT, NPASS, MODE, SPLIT, WAVES, X3, OCC>;
     size_t lds = C::LDS_BYTES;
     const size_t need = C::GROUPS == 1 ? 64 : (size_t)(TrunkLayout<H, L>::size + 16) * 4;
     if (lds < need) lds = need;
@@ -1174,13 +1187,13 @@ hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int gr
     return hipGetLastError();
 }
 
-template <int H, int L, int SPLIT, int WAVES, bool X3 = false>
+template <int H, int L, int SPLIT, int WAVES, bool X3 = false, int OCC = 1>
 bool launch2_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, const TrunkArgs& A,
                 int grid, hipStream_t st, hipError_t* e)
 {
 #define PINN_MCASE2(ACT, NP, MD)                                                        \
     if (act == ACT && npass == NP && mode == MD) {                                      \
-        *e = launch2_t<H, L, ACT, NP, MD, SPLIT, WAVES, X3>(theta, wpk, A, grid, st);        \
+        *e = launch2_t<H, L, ACT, NP, MD, SPLIT, WAVES, X3, OCC>(theta, wpk, A, grid, st);   \
         return true;                                                                    \
     }
     PINN_MCASE2(ACT_SIGMOID, 2, MODE_FWD) PINN_MCASE2(ACT_SIGMOID, 2, MODE_BWD)
@@ -1246,6 +1259,15 @@ static int mfma_generation()
     return gen;
 }
 
+// resident blocks per CU the chosen decomposition is built for (pinn_create sizes the persistent
+// grid and the per-block partial buffer with it)
+int mfma_blocks_per_cu(int H, int L, bool x3)
+{
+    const int gen = mfma_generation();
+    if (!x3 && H == 64 && L == 2 && gen >= 4 && gen <= 6) return gen - 2;
+    return 1;
+}
+
 size_t mfma_packed_weight_bytes(int H, int L) { return (size_t)2 * (L - 1) * 2 * H * H * 2; }  // hi + lo planes
 
 int mfma_partial_stride(int H, int L) { return 3 * H + (L - 1) * (H * H + H) + H + 1 + 3; }
@@ -1270,6 +1292,9 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
     if (H == 64 && L == 2) {
         if (gen == 2) return launch2_HL<64, 2, 2, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
         if (gen == 3) return launch2_HL<64, 2, 4, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+        if (gen == 4) return launch2_HL<64, 2, 4, 4, false, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
+        if (gen == 5) return launch2_HL<64, 2, 4, 4, false, 3>(act, npass, mode, theta, wpk, A, grid, st, err);
+        if (gen == 6) return launch2_HL<64, 2, 4, 4, false, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
         return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
     }
     if (H == 128 && L == 2) {

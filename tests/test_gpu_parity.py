@@ -9,6 +9,7 @@ vectors produced by the reference.  Tolerances (fp32 product vs fp64 reference):
 Integer/byte work (sampler points, masks, counts) is bit-exact.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -19,6 +20,7 @@ from pinn_for_quantum_wavefunction_surfaces_amd import capi
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
@@ -546,6 +548,69 @@ def test_one_message_pipelined_step_equals_plain_step(golden_dir):
     finally:
         if own:
             dist.destroy_process_group()
+
+
+def _dp_worker(rank, world, port, n_local, steps, out_dir):
+    """one data-parallel rank; both ranks share cuda:0 here, so the exchange runs over gloo
+    (RCCL refuses two ranks on one device) -- everything else is the production path"""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import pinn_for_quantum_wavefunction_surfaces_amd as pk
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        params = pk.set_params()
+        m = pk.NN_ion(params).to("cuda:0")
+        m.load_flat_params(torch.tensor(np.load(os.path.join(ROOT, "tests", "golden",
+                                                             "g1_weights.npz"))["ionHsym"]))
+        tr = pk.Trainer(m, params, n_points=n_local, lr=8e-3, device="cuda:0",
+                        plan=pk.DataParallelPlan(n_local))
+        assert tr.pipelined and tr.plan.world == world and tr.plan.first == rank * n_local
+        losses = []
+        for _ in range(steps):
+            tr.step()
+            losses.append(tr.losses()[0])
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), theta=tr.theta.cpu().numpy(),
+                 losses=np.array(losses), counts=tr.counts.cpu().numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_with_twice_the_points(tmp_path, golden_dir):
+    """the data-parallel step on real kernels: 2 ranks x 20 000 points (shards of one global
+    Philox stream, one all-reduce per step carrying gradient, losses and the next batch's
+    boundary counts) follow the trajectory of 1 rank x 40 000 points; ranks stay bit-identical
+    to each other"""
+    import socket
+    import torch.multiprocessing as mp
+    n_local, steps = 20000, 5
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, n_local, steps, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["theta"], r1["theta"]) and np.array_equal(r0["counts"], r1["counts"])
+    params = pkg.set_params()
+    m = pkg.NN_ion(params).to(DEV)
+    m.load_flat_params(torch.tensor(np.load(os.path.join(golden_dir, "g1_weights.npz"))["ionHsym"]))
+    tr = pkg.Trainer(m, params, n_points=2 * n_local, lr=8e-3, device=DEV)
+    one = []
+    for _ in range(steps):
+        tr.step()
+        one.append(tr.losses()[0])
+    th = tr.theta.cpu().numpy()
+    # Adam normalises the update, so fp32 summation-order differences in the gradient stay
+    # at round-off in theta over a few steps
+    assert np.abs(r0["theta"] - th).max() < 2e-5 * np.abs(th).max()
+    assert np.abs(r0["losses"] / np.array(one) - 1).max() < 1e-4
+    # the last sampled batch (one ahead) has the same global boundary-set sizes as the
+    # single-rank batch of that step
+    tr.resample()
+    assert tuple(r0["counts"]) == tuple(tr.counts.cpu().numpy())
 
 
 # ----------------------------------------------------------------------------- split-bf16 MFMA

@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--points", type=int, default=1000000, help="points per GPU per step")
     ap.add_argument("--arch", choices=sorted(ARCHS), default=DEFAULT_ARCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="primary workload only (profiling)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured HIP graph (helps below ~10^5 points)")
     args = ap.parse_args()
@@ -197,7 +198,7 @@ def main():
     # other workloads ride along as secondary records (same K, W, points): the split-bf16 variant
     # of the primary (fp32-grade parity on the MFMA pipe), the reference architecture on the
     # fp32 parity path, and the 2x128 trunk (highest matrix-pipe fraction)
-    others = [a for a in SECONDARY.get(args.arch, []) if a != args.arch]
+    others = [] if args.no_secondary else [a for a in SECONDARY.get(args.arch, []) if a != args.arch]
     sec = []
     for other in others:
         oarch = ARCHS[other]

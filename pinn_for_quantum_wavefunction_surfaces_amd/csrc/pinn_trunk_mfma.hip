@@ -32,6 +32,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pinn_math.h"
 #include "pinn_common.h"
 
@@ -606,7 +608,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_trunk_mfma(const float* __restric
 // [column][neuron] image of the weight-gradient contraction (ds_read_b64_tr_b16 straight
 // from the exchange buffer: no extra image writes).  Workgroup barriers separate the
 // exchange steps; all groups of a block run the same trip count so barriers always match.
-template <int H, int L, int SPLIT, int WAVES, bool X3 = false>
+// OCC: resident blocks per CU the kernel is built for; 0 = one block, never KEEP
+template <int H, int L, int SPLIT, int WAVES, bool X3 = false, int OCC = 1>
 struct M2Cfg {
     static constexpr int HT = H / 16, KC = H / 32, NW = L - 1;
     static constexpr int GROUPS = WAVES / SPLIT;
@@ -622,20 +625,25 @@ struct M2Cfg {
     static constexpr int EB1 = KC * 5 * 64 * 16;                  // bytes of one plane of an exchange buffer
     static constexpr int EB = NPL * EB1;
     static constexpr int SBYTES = SPLIT * 16 * 2 * 4;             // per-group partial (Sv, Sl)
-    static constexpr int GBYTES = (L - 1) * EB + EB + SBYTES;     // XB[0..L-2], YB, S
     static constexpr int ZBYTES = 1024;
     static constexpr size_t OFF_SMALL = (size_t)WPK * 2;
     static constexpr size_t OFF_ZERO = OFF_SMALL + NSMALL * 4;
     static constexpr size_t OFF_GRP = OFF_ZERO + ZBYTES;
+    // KEEP: every pass of the symmetric double pass has its own XB buffers (and register slot),
+    // so the reverse sweeps reuse the forward state instead of recomputing pass A -- when the
+    // second set fits the 160 KB of LDS (for all OCC resident blocks of a CU)
+    static constexpr bool KEEP = OCC >= 1 && OCC * (OFF_GRP + (size_t)GROUPS * (2 * (L - 1) * EB + EB + SBYTES)) <= 160 * 1024;
+    static constexpr int NXB = KEEP ? 2 : 1;
+    static constexpr int GBYTES = NXB * (L - 1) * EB + EB + SBYTES;   // XB[slot][0..L-2], YB, S
     static constexpr size_t LDS_BYTES = OFF_GRP + (size_t)GROUPS * GBYTES;
 };
 
 template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES, bool X3, int OCC>
-__global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(const float* __restrict__ theta,
+__global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k_trunk_mfma2(const float* __restrict__ theta,
                                                                       const __bf16* __restrict__ wpk_g,
                                                                       TrunkArgs A)
 {
-    using C = M2Cfg<H, L, SPLIT, WAVES, X3>;
+    using C = M2Cfg<H, L, SPLIT, WAVES, X3, OCC>;
     using Lay = TrunkLayout<H, L>;
     constexpr int HT = C::HT, KC = C::KC, NW = C::NW, NT = WAVES * 64, RT = C::RT;
     constexpr size_t WPLANE = (size_t)NW * 2 * H * H;   // elements of one weight plane
@@ -658,9 +666,11 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
     const int grp = wave / SPLIT, part = wave % SPLIT;
     const int g = lane >> 4, c = lane & 15;
     const lds_p gbase = lds0 + C::OFF_GRP + grp * C::GBYTES;
-    const lds_p XB = gbase;                             // [(L-1)] exchange buffers: outputs of layers 0..L-2
-    const lds_p YB = gbase + (L - 1) * C::EB;           // adjoint exchange buffer
-    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_GRP + (size_t)grp * C::GBYTES + (size_t)(L - 1) * C::EB + C::EB);   // [SPLIT][16][2]
+    constexpr bool KEEP = C::KEEP && NPASS == 2;
+    constexpr int NS = KEEP ? 2 : 1;                    // pass slots (registers and XB sets)
+    const lds_p XB = gbase;                             // [slot][(L-1)] exchange buffers: outputs of layers 0..L-2
+    const lds_p YB = gbase + C::NXB * (L - 1) * C::EB;  // adjoint exchange buffer
+    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_GRP + (size_t)grp * C::GBYTES + (size_t)C::NXB * (L - 1) * C::EB + C::EB);   // [SPLIT][16][2]
     const int lane16 = lane * 16;                       // lane-linear 16-byte fragment slot
     // transposed-read lane offset: row (8g + 4hh + (c>>2)) -> stream half (g>>1), point 8(g&1)+(c>>2);
     // 8-byte piece (c&1) of chunk ((c&3)>>1) of the tile: everything else is an immediate
@@ -765,11 +775,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
         const float lapF = inA[0][4] + A.P * inA[1][4];
 
         Tail<float> t;
-        float SvA = 0.f, SlA = 0.f;
-        constexpr int nstage = NPASS == 2 ? (MODE == MODE_BWD ? 3 : 2) : 1;
-#pragma unroll 1
-        for (int st = 0; st < nstage; st++) {
-            const bool useB = NPASS == 2 && st == 1;
+        // saved forward state per pass slot: (h, a_x, a_y, a_z, a_lap) of the own neurons, layers
+        // 1..L-1, as bf16 pairs (fp32 in split-bf16 mode: the adjoint algebra must not be the
+        // precision bottleneck) and the layer-0 activation.  With KEEP both passes keep their own
+        // slot (and their own XB buffers in LDS), so no pass is evaluated twice.
+        u32x2 sv[NS][X3 ? 1 : NW][RT][5];
+        f32x4 svf[NS][X3 ? NW : 1][RT][5];
+        f32x4 h0[NS][RT];
+        auto fwd = [&](const bool useB, auto SLc, float& Sv, float& Sl) {
+            constexpr int SL = decltype(SLc)::value;
+            const lds_p XBs = XB + SL * (L - 1) * C::EB;
             float in[2][5];
 #pragma unroll
             for (int s = 0; s < 5; s++) {
@@ -779,9 +794,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
             // =========================== forward ===========================
             // saved (h, a_x, a_y, a_z, a_lap) of the own neurons, layers 1..L-1: bf16 pairs, or
             // fp32 in split-bf16 mode (the adjoint algebra must not be the precision bottleneck)
-            u32x2 sv[X3 ? 1 : NW][RT][5];
-            f32x4 svf[X3 ? NW : 1][RT][5];
-            f32x4 h0[RT];   // layer-0 activation of the own neurons (its reverse pass needs it)
             {   // ---- layer 0 on the VALU (K = 2), own neurons only
                 f32x4 o[5][RT];
 #pragma unroll
@@ -803,17 +815,17 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
                     o[2][tt] = s1 * a[2];
                     o[3][tt] = s1 * a[3];
                     o[4][tt] = s1 * a[4] + s2 * q;
-                    h0[tt] = X3 ? s0 : unpack4(pack4(s0));   // bf16 mode: what the next layer saw
+                    h0[SL][tt] = X3 ? s0 : unpack4(pack4(s0));   // bf16 mode: what the next layer saw
                 }
 #pragma unroll
-                for (int s = 0; s < 5; s++) put_split(XB, s, o[s]);
+                for (int s = 0; s < 5; s++) put_split(XBs, s, o[s]);
             }
             __syncthreads();
-            float Sv = 0.f, Sl = 0.f;
+            Sv = 0.f; Sl = 0.f;
 #pragma unroll
             for (int l = 1; l < L; l++) {
                 const __bf16* wf = wsrc + (size_t)((l - 1) * 2 + 0) * H * H;
-                const lds_p xin = XB + (l - 1) * C::EB + lane16;
+                const lds_p xin = XBs + (l - 1) * C::EB + lane16;
                 f32x4 a[RT][5];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
@@ -847,13 +859,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
                     const f32x4 q = a[tt][1] * a[tt][1] + a[tt][2] * a[tt][2] + a[tt][3] * a[tt][3];
                     const f32x4 ol = s1 * a[tt][4] + s2 * q;
                     if (X3) {
-                        svf[l - 1][tt][0] = s0;
+                        svf[SL][l - 1][tt][0] = s0;
 #pragma unroll
-                        for (int s = 1; s < 5; s++) svf[l - 1][tt][s] = a[tt][s];
+                        for (int s = 1; s < 5; s++) svf[SL][l - 1][tt][s] = a[tt][s];
                     } else {
-                        sv[l - 1][tt][0] = pack4(s0);
+                        sv[SL][l - 1][tt][0] = pack4(s0);
 #pragma unroll
-                        for (int s = 1; s < 5; s++) sv[l - 1][tt][s] = pack4(a[tt][s]);
+                        for (int s = 1; s < 5; s++) sv[SL][l - 1][tt][s] = pack4(a[tt][s]);
                     }
                     if (l < L - 1) {
                         o[0][tt] = s0;
@@ -869,7 +881,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
                     }
                 }
                 if (l < L - 1) {
-                    const lds_p xout = XB + l * C::EB;
+                    const lds_p xout = XBs + l * C::EB;
 #pragma unroll
                     for (int s = 0; s < 5; s++) put_split(xout, s, o[s]);
                     __syncthreads();
@@ -883,29 +895,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
             Sv = 0.f; Sl = 0.f;
 #pragma unroll
             for (int pp = 0; pp < SPLIT; pp++) { Sv += SB[(pp * 16 + c) * 2]; Sl += SB[(pp * 16 + c) * 2 + 1]; }
-            const bool do_tail = NPASS == 1 || st == 1;
-            if (NPASS == 2 && st == 0) { SvA = Sv; SlA = Sl; }
-            if (do_tail) {
-                if (NPASS == 2) { Sv = SvA + A.P * Sv; Sl = SlA + A.P * Sl; }
-                const float N = A.out_scale * Sv + sbo[0];
-                const float lapN = A.out_scale * Sl;
-                tail<float>(N, lapN, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1, m2, A.invN, invN1,
-                            invN2, valid ? 1.0f : 0.0f, t);
-                if (MODE == MODE_FWD) {
-                    if (valid && g == 0 && part == 0) {
-                        if (A.psi) A.psi[idx] = t.psi;
-                        if (A.lap) A.lap[idx] = t.lap;
-                        if (A.res) A.res[idx] = t.res;
-                    }
-                } else {
-                    if (valid && g == 0 && part == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
-                    acc_pde += lead * t.l_pde;
-                    acc_bc1 += lead * t.l_bc1;
-                    acc_bc2 += lead * t.l_bc2;
-                    acc_bout += lead * t.Nb;
-                }
+        };
+        auto rev = [&](const bool useB, auto SLc) {
+            constexpr int SL = decltype(SLc)::value;
+            const lds_p XBs = XB + SL * (L - 1) * C::EB;
+            float in[2][5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                in[0][s] = useB ? inA[1][s] : inA[0][s];
+                in[1][s] = useB ? inA[0][s] : inA[1][s];
             }
-            if (!(MODE == MODE_BWD && (NPASS == 1 || st >= 1))) continue;   // uniform over the block
             // =========================== reverse ===========================
             const float pw = useB ? A.P : 1.0f;
             const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
@@ -915,13 +914,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
                 for (int tt = 0; tt < RT; tt++) {
                     f32x4 h, a[5];
                     if (X3) {
-                        h = svf[NW - 1][tt][0];
+                        h = svf[SL][NW - 1][tt][0];
 #pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = svf[NW - 1][tt][s];
+                        for (int s = 1; s < 5; s++) a[s] = svf[SL][NW - 1][tt][s];
                     } else {
-                        h = unpack4(sv[NW - 1][tt][0]);
+                        h = unpack4(sv[SL][NW - 1][tt][0]);
 #pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[NW - 1][tt][s]);
+                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[SL][NW - 1][tt][s]);
                     }
                     f32x4 s1, s2, s3;
                     act123v<ACT>(h, s1, s2, s3);
@@ -943,7 +942,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
             __syncthreads();
 #pragma unroll
             for (int l = L - 1; l >= 1; l--) {
-                const lds_p xin = XB + (l - 1) * C::EB;
+                const lds_p xin = XBs + (l - 1) * C::EB;
                 // ---- W_l-bar[own rows][all columns] += Y-bar (x) X, 32 of the 80 columns per phase,
                 //      both operands read transposed straight out of the exchange buffers
 #pragma unroll
@@ -1008,15 +1007,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
                         const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
 #pragma unroll
                         for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
-                        h = h0[tt];
+                        h = h0[SL][tt];
                     } else if (X3) {
-                        h = svf[l - 2][tt][0];
+                        h = svf[SL][l - 2][tt][0];
 #pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = svf[l - 2][tt][s];
+                        for (int s = 1; s < 5; s++) a[s] = svf[SL][l - 2][tt][s];
                     } else {
-                        h = unpack4(sv[l - 2][tt][0]);
+                        h = unpack4(sv[SL][l - 2][tt][0]);
 #pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[l - 2][tt][s]);
+                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[SL][l - 2][tt][s]);
                     }
                     f32x4 s1, s2, s3;
                     act123v<ACT>(h, s1, s2, s3);
@@ -1048,12 +1047,61 @@ __global__ __launch_bounds__(WAVES * 64, OCC * WAVES / 4) void k_trunk_mfma2(con
                     __syncthreads();
                 }
             }
-            // the next stage (or tile) overwrites the own XB slot, which the other waves of the
-            // group read in their weight-gradient phase: wait until they are through
+            // the next forward overwrites the own XB slot, which the other waves of the group
+            // read in their weight-gradient phase: wait until they are through
             __syncthreads();
+        };
+        auto finish = [&](float Sv, float Sl) {
+            const float N = A.out_scale * Sv + sbo[0];
+            const float lapN = A.out_scale * Sl;
+            tail<float>(N, lapN, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1, m2, A.invN, invN1,
+                        invN2, valid ? 1.0f : 0.0f, t);
+            if (MODE == MODE_FWD) {
+                if (valid && g == 0 && part == 0) {
+                    if (A.psi) A.psi[idx] = t.psi;
+                    if (A.lap) A.lap[idx] = t.lap;
+                    if (A.res) A.res[idx] = t.res;
+                }
+            } else {
+                if (valid && g == 0 && part == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+                acc_pde += lead * t.l_pde;
+                acc_bc1 += lead * t.l_bc1;
+                acc_bc2 += lead * t.l_bc2;
+                acc_bout += lead * t.Nb;
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, NS - 1>;
+        if (NPASS == 1) {
+            float Sv, Sl;
+            fwd(false, S0{}, Sv, Sl);
+            finish(Sv, Sl);
+            if (MODE == MODE_BWD) rev(false, S0{});
+        } else if (KEEP) {
+            float SvA, SlA, SvB, SlB;
+            fwd(false, S0{}, SvA, SlA);
+            fwd(true, S1{}, SvB, SlB);
+            finish(SvA + A.P * SvB, SlA + A.P * SlB);
+            if (MODE == MODE_BWD) {
+                rev(true, S1{});
+                rev(false, S0{});
+            }
+        } else {
+            // one slot: 0 = forward(f1,f2); 1 = forward(f2,f1) + tail + its reverse; 2 = forward(f1,f2)
+            // again + its reverse.  One copy of the code, three trips.
+            float SvA = 0.f, SlA = 0.f;
+            constexpr int nstage = MODE == MODE_BWD ? 3 : 2;
+#pragma unroll 1
+            for (int st = 0; st < nstage; st++) {
+                const bool useB = st == 1;
+                float Sv, Sl;
+                fwd(useB, S0{}, Sv, Sl);
+                if (st == 0) { SvA = Sv; SlA = Sl; }
+                if (st == 1) finish(SvA + A.P * Sv, SlA + A.P * Sl);
+                if (MODE == MODE_BWD && st >= 1) rev(useB, S0{});
+            }
         }
     }
-
     if (MODE == MODE_FWD) return;
     // =========================== block reduction ===========================
     __syncthreads();
@@ -1168,7 +1216,7 @@ template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES, bool
 hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
 {
     using C1 = MCfg<H, L>;
-    using C = M2Cfg<H, L, SPLIT, WAVES, X3>;
+    using C = M2Cfg<H, L, SPLIT, WAVES, X3, OCC>;
     const int nfrag = C1::NW * 2 * C1::HT * C1::KC * 64;
     hipLaunchKernelGGL((k_pack_weights<H, L, X3>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
     hipError_t e = hipGetLastError();
@@ -1248,13 +1296,14 @@ bool launch_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, co
 bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
 bool mfma_x3_supported(int H, int L) { return (H == 64 || H == 128) && L == 2; }
 
-// A/B switch for measurements (see launch_trunk_mfma): PINN_MFMA_GEN = 1 (default), 2, 3.
+// A/B switch for measurements (see launch_trunk_mfma): PINN_MFMA_GEN = 0 (default: the fastest
+// measured decomposition), 1..6 = alternatives.
 static int mfma_generation()
 {
     static int gen = -1;
     if (gen < 0) {
         const char* e = getenv("PINN_MFMA_GEN");
-        gen = (e && e[0] >= '1' && e[0] <= '9') ? e[0] - '0' : 1;
+        gen = (e && e[0] >= '1' && e[0] <= '9') ? e[0] - '0' : 0;
     }
     return gen;
 }
@@ -1264,7 +1313,8 @@ static int mfma_generation()
 int mfma_blocks_per_cu(int H, int L, bool x3)
 {
     const int gen = mfma_generation();
-    if (!x3 && H == 64 && L == 2 && gen >= 4 && gen <= 6) return gen - 2;
+    if (H == 64 && L == 2 && !x3) return gen == 0 ? 2 : (gen == 5 ? 3 : (gen == 6 ? 4 : 1));
+    if (H == 64 && L == 2 && x3) return gen == 4 ? 2 : 1;
     return 1;
 }
 
@@ -1277,25 +1327,32 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
                        hipError_t* err)
 {
     __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
+    // <H, L, SPLIT, WAVES, X3, OCC>: SPLIT waves share a 16-point tile, WAVES per block, OCC
+    // resident blocks per CU.  Defaults are the fastest measured decomposition per shape (1M points,
+    // MI355X, kernel ms); PINN_MFMA_GEN = 1..6 selects the alternatives for A/B measurements:
+    //   2x64 : <4,4> x 2 blocks/CU 0.72 | point-split gen-1 0.76 | <4,8> 0.74 | <2,8> (spills)
+    //   2x128: <8,8> 1.88 | <4,4> 2.7          4x64: <2,4> 2.27 | <4,8> 4.2
+    //   4x128: <4,4> 21 | <8,8> 30  (both spill > 1 KB/lane: functional, not tuned)
+    const int gen = mfma_generation();
     if (x3) {   // split-bf16 operands (3 MFMAs per product): neuron-split kernel only
-        if (H == 64 && L == 2) return launch2_HL<64, 2, 4, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
-        if (H == 128 && L == 2) return launch2_HL<128, 2, 8, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
+        if (H == 64 && L == 2) {
+            if (gen == 4) return launch2_HL<64, 2, 4, 4, true, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
+            return launch2_HL<64, 2, 4, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
+        }
+        if (H == 128 && L == 2) {
+            // both passes resident costs 480 B/lane of spills here: 7.0 ms against 5.2 ms
+            if (gen == 2) return launch2_HL<128, 2, 8, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
+            return launch2_HL<128, 2, 8, 8, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
+        }
         return false;
     }
-    // <H, L, SPLIT, WAVES>: SPLIT waves share a 16-point tile, WAVES per block.  Defaults are the
-    // fastest measured decomposition per shape (1M points, MI355X, kernel ms):
-    //   2x64 : point-split gen-1 0.90-0.95 | <2,8> 1.11 | <4,8> 0.97
-    //   2x128: <8,8> 2.57 | <4,4> 2.73          4x64: <2,4> 2.37 | <4,8> 4.20
-    //   4x128: <4,4> 27.6 | <8,8> 29.8  (both spill > 1 KB/lane: functional, not tuned)
-    // PINN_MFMA_GEN=2/3 selects the alternatives for A/B measurements.
-    const int gen = mfma_generation();
     if (H == 64 && L == 2) {
+        if (gen == 1) return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
         if (gen == 2) return launch2_HL<64, 2, 2, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
         if (gen == 3) return launch2_HL<64, 2, 4, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
-        if (gen == 4) return launch2_HL<64, 2, 4, 4, false, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
         if (gen == 5) return launch2_HL<64, 2, 4, 4, false, 3>(act, npass, mode, theta, wpk, A, grid, st, err);
         if (gen == 6) return launch2_HL<64, 2, 4, 4, false, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-        return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
+        return launch2_HL<64, 2, 4, 4, false, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
     }
     if (H == 128 && L == 2) {
         if (gen == 2) return launch2_HL<128, 2, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);

@@ -618,9 +618,16 @@ struct M2Cfg {
     static constexpr int NPL = X3 ? 2 : 1;                        // operand planes (hi, lo)
     static constexpr int WPK_ALL = NPL * NW * 2 * H * H;          // bf16 elements
     // packed weights are staged in LDS when they fit beside the exchange buffers; otherwise
-    // (4x128: 192 KB) the A fragments are read from global memory, where they stay L2-resident
+    // (4x128: 192 KB) they are streamed through two one-matrix LDS buffers (WSTREAM), or, in
+    // split-bf16 mode, the A fragments are read from global memory, where they stay L2-resident
     static constexpr bool WLDS = (size_t)WPK_ALL * 2 <= 64 * 1024;
-    static constexpr int WPK = WLDS ? WPK_ALL : 0;
+    // WSTREAM (bf16 only): one layer matrix at a time, double-buffered in LDS by LDS-DMA
+    // (global_load_lds_dwordx4) while the previous layer computes; the packed set stays in L2
+    static constexpr bool WSTREAM = !WLDS && !X3;
+    static constexpr int WPK = WLDS ? WPK_ALL : (WSTREAM ? 2 * H * H : 0);
+    // deep wide trunks keep the k loop rolled: unrolled, the scheduler hoists all 20 B-fragment
+    // reads of a layer and the kernel spills
+    static constexpr int KCU = (L > 2 && H >= 128) ? 1 : KC;
     static constexpr int NSMALL = 3 * H + NW * H + H + 4;         // floats
     static constexpr int EB1 = KC * 5 * 64 * 16;                  // bytes of one plane of an exchange buffer
     static constexpr int EB = NPL * EB1;
@@ -722,8 +729,25 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
         for (int k = threadIdx.x; k < C::ZBYTES / 4; k += NT)
             reinterpret_cast<unsigned*>(lds_raw + C::OFF_ZERO)[k] = 0u;
     }
-    __syncthreads();
     const __bf16* wsrc = C::WLDS ? wpk : wpk_g;   // one provenance per instantiation
+    // ---- weight streaming: matrix use k reads LDS buffer k & 1; at the start of use k every wave
+    // copies its share of use k+1's matrix into the other buffer (free since the barrier that ended
+    // use k-1); the barrier that ends use k drains the copy (vmcnt(0)) before anyone reads it.
+    constexpr bool WSTREAM = C::WSTREAM;
+    constexpr int WBUF = H * H * 2;                     // bytes of one matrix
+    int wuse = 0;
+    auto wstage = [&](int mat, int into) {              // mat = (l-1)*2 + dir, < 0: nothing follows
+        if (!WSTREAM || mat < 0) return;
+        const __bf16* src = wpk_g + (size_t)mat * H * H;
+        const lds_p dst = lds0 + (into & 1) * WBUF;
+        for (int f = wave; f < HT * KC; f += WAVES)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + ((size_t)f * 64 + lane) * 8),
+                (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+    };
+    auto wcur = [&]() { return reinterpret_cast<const __bf16*>(lds_raw + (wuse & 1) * WBUF); };
+    wstage(0, 0);                                       // first use: layer 1 forward
+    __syncthreads();
 
     // ---- persistent gradient state (own row tiles RT*part + tt, tt < RT)
     f32x4 wacc[NW][RT][HT];
@@ -782,7 +806,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
         u32x2 sv[NS][X3 ? 1 : NW][RT][5];
         f32x4 svf[NS][X3 ? NW : 1][RT][5];
         f32x4 h0[NS][RT];
-        auto fwd = [&](const bool useB, auto SLc, float& Sv, float& Sl) {
+        auto fwd = [&](const bool useB, auto SLc, float& Sv, float& Sl, const int wnext) {
             constexpr int SL = decltype(SLc)::value;
             const lds_p XBs = XB + SL * (L - 1) * C::EB;
             float in[2][5];
@@ -824,7 +848,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
             Sv = 0.f; Sl = 0.f;
 #pragma unroll
             for (int l = 1; l < L; l++) {
-                const __bf16* wf = wsrc + (size_t)((l - 1) * 2 + 0) * H * H;
+                wstage(l < L - 1 ? l * 2 : wnext, wuse + 1);
+                const __bf16* wf = WSTREAM ? wcur() : wsrc + (size_t)((l - 1) * 2 + 0) * H * H;
                 const lds_p xin = XBs + (l - 1) * C::EB + lane16;
                 f32x4 a[RT][5];
 #pragma unroll
@@ -833,7 +858,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
                     for (int s = 1; s < 5; s++) a[tt][s] = splat(0.f);
                 }
-#pragma unroll
+#pragma unroll C::KCU
                 for (int kc = 0; kc < KC; kc++) {
                     bf16x8 wa[RT], wl[RT];
 #pragma unroll
@@ -886,6 +911,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     for (int s = 0; s < 5; s++) put_split(xout, s, o[s]);
                     __syncthreads();
                 }
+                if (WSTREAM) wuse++;
             }
             // ---- combine the partial output sums of the group's waves (fixed order)
             Sv = xg_sum(Sv);
@@ -896,7 +922,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
             for (int pp = 0; pp < SPLIT; pp++) { Sv += SB[(pp * 16 + c) * 2]; Sl += SB[(pp * 16 + c) * 2 + 1]; }
         };
-        auto rev = [&](const bool useB, auto SLc) {
+        auto rev = [&](const bool useB, auto SLc, const int wnext) {
             constexpr int SL = decltype(SLc)::value;
             const lds_p XBs = XB + SL * (L - 1) * C::EB;
             float in[2][5];
@@ -943,6 +969,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
             for (int l = L - 1; l >= 1; l--) {
                 const lds_p xin = XBs + (l - 1) * C::EB;
+                wstage(l - 1 >= 1 ? (l - 2) * 2 + 1 : wnext, wuse + 1);
                 // ---- W_l-bar[own rows][all columns] += Y-bar (x) X, 32 of the 80 columns per phase,
                 //      both operands read transposed straight out of the exchange buffers
 #pragma unroll
@@ -972,13 +999,13 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     }
                 }
                 // ---- adjoint of layer l's input for the own neurons, then layer l-1's activation adjoint
-                const __bf16* wb = wsrc + (size_t)((l - 1) * 2 + 1) * H * H;
+                const __bf16* wb = WSTREAM ? wcur() : wsrc + (size_t)((l - 1) * 2 + 1) * H * H;
                 f32x4 ob[RT][5];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++)
 #pragma unroll
                     for (int s = 0; s < 5; s++) ob[tt][s] = splat(0.f);
-#pragma unroll
+#pragma unroll C::KCU
                 for (int kc = 0; kc < KC; kc++) {
                     bf16x8 wa[RT], wl[RT];
 #pragma unroll
@@ -1046,6 +1073,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     for (int s = 0; s < 5; s++) put_split(YB, s, yo[s]);
                     __syncthreads();
                 }
+                if (WSTREAM) wuse++;
             }
             // the next forward overwrites the own XB slot, which the other waves of the group
             // read in their weight-gradient phase: wait until they are through
@@ -1072,19 +1100,23 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, NS - 1>;
+        // matrix that the use after a pass's last one needs (weight streaming): layer 1 forward of
+        // the next pass / tile, the last layer's transpose when a reverse sweep follows, or nothing
+        constexpr int F1 = 0, BL = (L - 2) * 2 + 1;
+        const int F1n = itx == iters - 1 ? -1 : F1;     // ... of the next tile
         if (NPASS == 1) {
             float Sv, Sl;
-            fwd(false, S0{}, Sv, Sl);
+            fwd(false, S0{}, Sv, Sl, MODE == MODE_BWD ? BL : F1n);
             finish(Sv, Sl);
-            if (MODE == MODE_BWD) rev(false, S0{});
+            if (MODE == MODE_BWD) rev(false, S0{}, F1n);
         } else if (KEEP) {
             float SvA, SlA, SvB, SlB;
-            fwd(false, S0{}, SvA, SlA);
-            fwd(true, S1{}, SvB, SlB);
+            fwd(false, S0{}, SvA, SlA, F1);
+            fwd(true, S1{}, SvB, SlB, MODE == MODE_BWD ? BL : F1n);
             finish(SvA + A.P * SvB, SlA + A.P * SlB);
             if (MODE == MODE_BWD) {
-                rev(true, S1{});
-                rev(false, S0{});
+                rev(true, S1{}, BL);
+                rev(false, S0{}, F1n);
             }
         } else {
             // one slot: 0 = forward(f1,f2); 1 = forward(f2,f1) + tail + its reverse; 2 = forward(f1,f2)
@@ -1094,11 +1126,13 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll 1
             for (int st = 0; st < nstage; st++) {
                 const bool useB = st == 1;
+                const bool reverse = MODE == MODE_BWD && st >= 1;
+                const int after = st == nstage - 1 ? F1n : F1;
                 float Sv, Sl;
-                fwd(useB, S0{}, Sv, Sl);
+                fwd(useB, S0{}, Sv, Sl, reverse ? BL : after);
                 if (st == 0) { SvA = Sv; SlA = Sl; }
                 if (st == 1) finish(SvA + A.P * Sv, SlA + A.P * Sl);
-                if (MODE == MODE_BWD && st >= 1) rev(useB, S0{});
+                if (reverse) rev(useB, S0{}, after);
             }
         }
     }
@@ -1332,7 +1366,8 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
     // MI355X, kernel ms); PINN_MFMA_GEN = 1..6 selects the alternatives for A/B measurements:
     //   2x64 : <4,4> x 2 blocks/CU 0.72 | point-split gen-1 0.76 | <4,8> 0.74 | <2,8> (spills)
     //   2x128: <8,8> 1.88 | <4,4> 2.7          4x64: <2,4> 2.27 | <4,8> 4.2
-    //   4x128: <4,4> 21 | <8,8> 30  (both spill > 1 KB/lane: functional, not tuned)
+    //   4x128: <4,4> 11.8 | <8,8> 15.4  (weights streamed through LDS; both still spill ~0.5 KB/lane:
+    //          the 3 x 128 x 128 fp32 gradient accumulators alone are 38 % of a CU's registers)
     const int gen = mfma_generation();
     if (x3) {   // split-bf16 operands (3 MFMAs per product): neuron-split kernel only
         if (H == 64 && L == 2) {

@@ -628,6 +628,10 @@ struct M2Cfg {
     // deep wide trunks keep the k loop rolled: unrolled, the scheduler hoists all 20 B-fragment
     // reads of a layer and the kernel spills
     static constexpr int KCU = (L > 2 && H >= 128) ? 1 : KC;
+    // explicit software pipeline of the GEMM phases: the operand fragments of k-chunk kc+1 are read
+    // from LDS before the MFMAs of chunk kc issue (scheduling fences keep that order), so the
+    // matrix pipe does not sit behind one LDS round trip per instruction
+    static constexpr bool PIPE = !X3 && KCU == KC;
     static constexpr int NSMALL = 3 * H + NW * H + H + 4;         // floats
     static constexpr int EB1 = KC * 5 * 64 * 16;                  // bytes of one plane of an exchange buffer
     static constexpr int EB = NPL * EB1;
@@ -858,6 +862,28 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
                     for (int s = 1; s < 5; s++) a[tt][s] = splat(0.f);
                 }
+                if constexpr (C::PIPE) {
+                    bf16x8 wq[2][RT], xq[2][5];
+                    auto fetch = [&](int kc, bf16x8 (&w)[RT], bf16x8 (&x)[5]) {
+#pragma unroll
+                        for (int tt = 0; tt < RT; tt++)
+                            w[tt] = *reinterpret_cast<const bf16x8*>(wf + (((RT * part + tt) * KC + kc) * 64 + lane) * 8);
+#pragma unroll
+                        for (int s = 0; s < 5; s++)
+                            x[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(xin + (kc * 5 + s) * 64 * 16);
+                    };
+                    fetch(0, wq[0], xq[0]);
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        if (kc + 1 < KC) fetch(kc + 1, wq[(kc + 1) & 1], xq[(kc + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int s = 0; s < 5; s++)
+#pragma unroll
+                            for (int tt = 0; tt < RT; tt++) a[tt][s] = mfma(wq[kc & 1][tt], xq[kc & 1][s], a[tt][s]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll C::KCU
                 for (int kc = 0; kc < KC; kc++) {
                     bf16x8 wa[RT], wl[RT];
@@ -875,6 +901,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
                         for (int tt = 0; tt < RT; tt++) a[tt][s] = mfma3(wa[tt], wl[tt], xb, xl, a[tt][s]);
                     }
+                }
                 }
                 f32x4 o[5][RT];
 #pragma unroll
@@ -989,6 +1016,19 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                         fy[tt] = frag(YB, RT * part + tt, 0);
                         fyl[tt] = X3 ? frag(YB, RT * part + tt, 1) : fy[tt];
                     }
+                    if constexpr (C::PIPE) {
+                        bf16x8 fq[2];
+                        fq[0] = frag(xin, 0, 0);
+#pragma unroll
+                        for (int it = 0; it < HT; it++) {
+                            if (it + 1 < HT) fq[(it + 1) & 1] = frag(xin, it + 1, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int tt = 0; tt < RT; tt++)
+                                wacc[l - 1][tt][it] = mfma(fy[tt], fq[it & 1], wacc[l - 1][tt][it]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
 #pragma unroll
                     for (int it = 0; it < HT; it++) {
                         const bf16x8 fx = frag(xin, it, 0);
@@ -996,6 +1036,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
                         for (int tt = 0; tt < RT; tt++)
                             wacc[l - 1][tt][it] = mfma3(fy[tt], fyl[tt], fx, fxl, wacc[l - 1][tt][it]);
+                    }
                     }
                 }
                 // ---- adjoint of layer l's input for the own neurons, then layer l-1's activation adjoint
@@ -1005,6 +1046,28 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                 for (int tt = 0; tt < RT; tt++)
 #pragma unroll
                     for (int s = 0; s < 5; s++) ob[tt][s] = splat(0.f);
+                if constexpr (C::PIPE) {
+                    bf16x8 wq[2][RT], yq[2][5];
+                    auto fetch = [&](int kc, bf16x8 (&w)[RT], bf16x8 (&y)[5]) {
+#pragma unroll
+                        for (int tt = 0; tt < RT; tt++)
+                            w[tt] = *reinterpret_cast<const bf16x8*>(wb + (((RT * part + tt) * KC + kc) * 64 + lane) * 8);
+#pragma unroll
+                        for (int s = 0; s < 5; s++)
+                            y[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(YB + lane16 + (kc * 5 + s) * 64 * 16);
+                    };
+                    fetch(0, wq[0], yq[0]);
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        if (kc + 1 < KC) fetch(kc + 1, wq[(kc + 1) & 1], yq[(kc + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int s = 0; s < 5; s++)
+#pragma unroll
+                            for (int tt = 0; tt < RT; tt++) ob[tt][s] = mfma(wq[kc & 1][tt], yq[kc & 1][s], ob[tt][s]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll C::KCU
                 for (int kc = 0; kc < KC; kc++) {
                     bf16x8 wa[RT], wl[RT];
@@ -1022,6 +1085,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
                         for (int tt = 0; tt < RT; tt++) ob[tt][s] = mfma3(wa[tt], wl[tt], yb, yl, ob[tt][s]);
                     }
+                }
                 }
                 f32x4 yo[5][RT];
 #pragma unroll

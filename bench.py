@@ -63,8 +63,8 @@ ARCHS["wide128x3"] = dict(ARCHS["wide128"], precision="bf16x3", dtype="bf16x3",
                           label="2x128 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
                                 "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
 # HBM bytes per launch of each workload's trunk kernel from rocprofv3 PMC passes (FETCH_SIZE x 2 --
-# the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r01z_final_default_bench.md)
-TRAFFIC = {"wide64": 38.3e6, "wide64x3": 40.1e6, "ref16": 33.2e6, "wide128": 80.3e6}
+# the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r01zz_final_default_bench.md)
+TRAFFIC = {"wide64": 71.7e6, "wide64x3": 40.1e6, "ref16": 33.2e6, "wide128": 81.4e6}
 DEFAULT_ARCH = "wide64"
 SECONDARY = {"wide64": ["wide64x3", "ref16", "wide128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
              "wide128": ["wide128x3"], "wide128x3": ["wide128"]}
@@ -236,7 +236,8 @@ def main():
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": TRAFFIC.get(args.arch),
-                         "traffic_source": "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r01z", "kernel": "k_trunk" if arch["dtype"] == "f32" else "k_trunk_mfma",
+                         "traffic_source": "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r01zz",
+                         "kernel": "k_trunk" if arch["dtype"] == "f32" else "k_trunk_mfma2",
                          "kernel_ms": trunk_ms, "flops_per_point": fl_trunk,
                          "note": ("fp32 path: vector and f32-matrix peaks are both 157.3 TFLOP/s"
                                   if arch["dtype"] == "f32" else

@@ -632,6 +632,9 @@ struct M2Cfg {
     // from LDS before the MFMAs of chunk kc issue (scheduling fences keep that order), so the
     // matrix pipe does not sit behind one LDS round trip per instruction
     static constexpr bool PIPE = !X3 && KCU == KC;
+    // saved pre-activations as fp32 (no pack on the way in, no unpack in the reverse sweep: ~30 VALU
+    // instructions less per row tile and pass) where the registers are there; bf16 pairs otherwise
+    static constexpr bool SVF32 = X3 || (H == 64 && L == 2);
     static constexpr int NSMALL = 3 * H + NW * H + H + 4;         // floats
     static constexpr int EB1 = KC * 5 * 64 * 16;                  // bytes of one plane of an exchange buffer
     static constexpr int EB = NPL * EB1;
@@ -678,6 +681,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
     const int g = lane >> 4, c = lane & 15;
     const lds_p gbase = lds0 + C::OFF_GRP + grp * C::GBYTES;
     constexpr bool KEEP = C::KEEP && NPASS == 2;
+    constexpr bool SVF = C::SVF32;
     constexpr int NS = KEEP ? 2 : 1;                    // pass slots (registers and XB sets)
     const lds_p XB = gbase;                             // [slot][(L-1)] exchange buffers: outputs of layers 0..L-2
     const lds_p YB = gbase + C::NXB * (L - 1) * C::EB;  // adjoint exchange buffer
@@ -804,11 +808,11 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 
         Tail<float> t;
         // saved forward state per pass slot: (h, a_x, a_y, a_z, a_lap) of the own neurons, layers
-        // 1..L-1, as bf16 pairs (fp32 in split-bf16 mode: the adjoint algebra must not be the
-        // precision bottleneck) and the layer-0 activation.  With KEEP both passes keep their own
+        // 1..L-1, as fp32 or bf16 pairs (C::SVF32; always fp32 in split-bf16 mode: the adjoint algebra
+        // must not be the precision bottleneck) and the layer-0 activation.  With KEEP both passes keep their own
         // slot (and their own XB buffers in LDS), so no pass is evaluated twice.
-        u32x2 sv[NS][X3 ? 1 : NW][RT][5];
-        f32x4 svf[NS][X3 ? NW : 1][RT][5];
+        u32x2 sv[NS][SVF ? 1 : NW][RT][5];
+        f32x4 svf[NS][SVF ? NW : 1][RT][5];
         f32x4 h0[NS][RT];
         auto fwd = [&](const bool useB, auto SLc, float& Sv, float& Sl, const int wnext) {
             constexpr int SL = decltype(SLc)::value;
@@ -843,7 +847,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     o[2][tt] = s1 * a[2];
                     o[3][tt] = s1 * a[3];
                     o[4][tt] = s1 * a[4] + s2 * q;
-                    h0[SL][tt] = X3 ? s0 : unpack4(pack4(s0));   // bf16 mode: what the next layer saw
+                    h0[SL][tt] = s0;
                 }
 #pragma unroll
                 for (int s = 0; s < 5; s++) put_split(XBs, s, o[s]);
@@ -910,7 +914,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     act012v<ACT>(a[tt][0], s0, s1, s2);
                     const f32x4 q = a[tt][1] * a[tt][1] + a[tt][2] * a[tt][2] + a[tt][3] * a[tt][3];
                     const f32x4 ol = s1 * a[tt][4] + s2 * q;
-                    if (X3) {
+                    if (SVF) {
                         svf[SL][l - 1][tt][0] = s0;
 #pragma unroll
                         for (int s = 1; s < 5; s++) svf[SL][l - 1][tt][s] = a[tt][s];
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
                     f32x4 h, a[5];
-                    if (X3) {
+                    if (SVF) {
                         h = svf[SL][NW - 1][tt][0];
 #pragma unroll
                         for (int s = 1; s < 5; s++) a[s] = svf[SL][NW - 1][tt][s];
@@ -1099,7 +1103,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
                         for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
                         h = h0[SL][tt];
-                    } else if (X3) {
+                    } else if (SVF) {
                         h = svf[SL][l - 2][tt][0];
 #pragma unroll
                         for (int s = 1; s < 5; s++) a[s] = svf[SL][l - 2][tt][s];

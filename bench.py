@@ -22,8 +22,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def trunk_flops_per_point(H, L, n_pass, S=5):
-    """fwd+bwd MACs per pass 4SH + 3S(L-1)H^2 + 6H, 2 flop per MAC."""
+def trunk_flops_per_point(H, L, n_pass, S=5, fine_tune=False):
+    """fwd+bwd MACs per pass 4SH + 3S(L-1)H^2 + 6H, 2 flop per MAC; frozen trunk
+    (fine-tune): the forward sweep only, S(2H + (L-1)H^2) + 2H MACs per pass."""
+    if fine_tune:
+        return 2.0 * n_pass * (S * (2 * H + (L - 1) * H * H) + 2 * H)
     return 2.0 * n_pass * (4 * S * H + 3 * S * (L - 1) * H * H + 6 * H)
 
 
@@ -44,6 +47,11 @@ ARCHS = {
                    label="2x64 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "
                          "accumulate, seeded random init"),
 }
+# BASELINE config 4 (fine-tune sweep, poc/main.py:384-387 freezeUnits): warm start from the published
+# weights, trunk and gate frozen (forward-only trunk sweep, MODE_HEAD), R ~ U(0.5, 4), lr 5e-4
+ARCHS["ref16ft"] = dict(ARCHS["ref16"], fine_tune=True,
+                        label="reference arch, fine-tune mode: trunk + gate frozen, only the E-net trains "
+                              "(forward-only trunk sweep), R in [0.5, 4], ionHsym weights, fp32")
 ARCHS["wide128"] = dict(H=128, L=2, HE=32, HG=10, act=1, n_pass=2, out_scale=1.0, precision="bf16",
                         act_name="tanh", peak=2500.0, dtype="bf16",
                         label="2x128 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "
@@ -66,7 +74,7 @@ ARCHS["wide128x3"] = dict(ARCHS["wide128"], precision="bf16x3", dtype="bf16x3",
 # the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r01zz_final_default_bench.md)
 TRAFFIC = {"wide64": 71.7e6, "wide64x3": 40.1e6, "ref16": 33.2e6, "wide128": 81.4e6}
 DEFAULT_ARCH = "wide64"
-SECONDARY = {"wide64": ["wide64x3", "ref16", "wide128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
+SECONDARY = {"wide64": ["wide64x3", "ref16", "ref16ft", "wide128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
              "wide128": ["wide128x3"], "wide128x3": ["wide128"]}
 # tolerances the GPU parity tests hold each path to, against the fp64 oracle / reference vectors
 # (tests/test_gpu_parity.py); "observed" = what those tests print on MI355X
@@ -162,7 +170,7 @@ def main():
     torch.manual_seed(12345)
     model = pkg.NN_ion(params, arch["H"], arch["HE"], arch["HG"], n_hidden=arch["L"],
                        act=arch["act_name"], precision=arch["precision"]).to(dev)
-    if args.arch == "ref16":
+    if args.arch.startswith("ref16"):
         w = np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))
         model.load_flat_params(torch.tensor(w["ionHsym"]))
     theta0 = model.flat_params(dtype=torch.float64).cpu().numpy()
@@ -176,7 +184,12 @@ def main():
 
     def run(model, arch_name):
         """W untimed + K timed steps of one workload; returns (seconds, trunk kernel ms, losses)"""
-        tr = pkg.Trainer(model, params, n_points=args.points, lr=8e-3, seed=12345, device=dev, plan=plan)
+        p, lr = params, 8e-3
+        if ARCHS[arch_name].get("fine_tune"):
+            model.freezeDecayUnit()
+            model.freezeBase()
+            p, lr = dict(params, RxL=0.5), 5e-4
+        tr = pkg.Trainer(model, p, n_points=args.points, lr=lr, seed=12345, device=dev, plan=plan)
         if args.graph:
             step = tr.capture_graph(warmup=max(args.warmup, 1))
             tr.h.profile_enable(1)          # events recorded at capture time only
@@ -205,7 +218,7 @@ def main():
         torch.manual_seed(12345)
         omodel = pkg.NN_ion(params, oarch["H"], oarch["HE"], oarch["HG"], n_hidden=oarch["L"],
                             act=oarch["act_name"], precision=oarch["precision"]).to(dev)
-        if other == "ref16":
+        if other.startswith("ref16"):
             omodel.load_flat_params(torch.tensor(
                 np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))["ionHsym"]))
         odt, otrunk_ms, olosses = run(omodel, other)
@@ -213,7 +226,7 @@ def main():
         del omodel
     if rank == 0:
         n_total = args.points * world
-        fl_trunk = trunk_flops_per_point(arch["H"], arch["L"], arch["n_pass"])
+        fl_trunk = trunk_flops_per_point(arch["H"], arch["L"], arch["n_pass"], fine_tune=arch.get("fine_tune", False))
         achieved = fl_trunk * args.points / (trunk_ms * 1e-3) / 1e12
         peak = arch["peak"]
         out = {
@@ -247,7 +260,7 @@ def main():
         out["parity"] = PARITY[arch["precision"]]
         out["secondary"] = []
         for other, oarch, odt, otrunk_ms, olosses in sec:
-            ofl = trunk_flops_per_point(oarch["H"], oarch["L"], oarch["n_pass"])
+            ofl = trunk_flops_per_point(oarch["H"], oarch["L"], oarch["n_pass"], fine_tune=oarch.get("fine_tune", False))
             oach = ofl * args.points / (otrunk_ms * 1e-3) / 1e12
             out["secondary"].append({
                 "workload": oarch["label"], "arch": other, "dtype": oarch["dtype"],

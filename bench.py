@@ -153,13 +153,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("PINN_FORCE_DIST") == "1"   # the latter: RCCL sanity at N=1
+    # rehearsal of the N > 1 code path on a one-GPU box: all ranks on cuda:0, exchange over gloo
+    # (RCCL refuses two ranks on one device).  Never used by the driver's runs.
+    rehearsal = os.environ.get("PINN_REHEARSE_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

@@ -57,10 +57,10 @@ class DataParallelPlan:
         counts_local (int64[2], the NEXT batch's local BC set sizes) travel in the two spare
         floats and come back summed in counts_global (int64[2]).  Needs n_global < 2^24."""
         assert self.n_global < (1 << 24)
-        buf[-2:] = counts_local.to(torch.float32)
+        buf[-2:].copy_(counts_local)            # int64 -> fp32 inside the copy kernel (exact < 2^24)
         if self.collectives:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        counts_global.copy_(buf[-2:].round().to(torch.int64))
+        counts_global.copy_(buf[-2:])           # sums of integers below 2^24 are exact in fp32
         return buf
 
     def max_over_ranks(self, seconds, device):

@@ -1,33 +1,41 @@
-// pinn_trunk_mfma.hip -- fused trunk kernel for wide architectures on the bf16 matrix cores.
+// pinn_trunk_mfma.hip -- fused trunk kernels for wide architectures on the bf16 matrix cores.
 //
 // Same mathematics as k_trunk in pinn_kernels.hip (five streams per neuron, hand-derived
 // adjoint; train.py:41-57,71 / poc/main.py:247-303,341-355,403), different execution shape:
 // at H >= 64 the H x H layers are dense GEMMs, so they run on v_mfma_f32_16x16x32_bf16.
 //
-// Shape ("transposed, point-split"):
-//   * a workgroup is 4 waves; each wave owns 16 points per tile and ALL H neurons.
+// Common to both kernels below:
 //   * every GEMM is computed transposed, D[neuron][column] with column = (stream, point):
 //     the five streams of one point are five 16-column tiles, so lane (g = lane>>4,
-//     c = lane&15) holds, for point c, the neurons 16*jt + 4*g + r (r = 0..3) of every row
+//     c = lane&15) holds, for point c, the neurons 16*jt + 4*g + r (r = 0..3) of a row
 //     tile jt and all five streams of them in its own registers: activation and adjoint
 //     algebra are purely lane-local.
 //   * the accumulator layout of one layer IS the B-operand layout of the next (and of the
 //     reverse pass): a lane's 8 bf16 of a k-chunk are its 4 neurons of row tiles 2kc and
 //     2kc+1.  That fixes a permutation of the contraction index, applied once to the
-//     weights when they are packed (k_pack_weights), so activations never leave registers
-//     between layers: no LDS round trip, no shuffles.
-//   * weights (A operands) are staged once per block in LDS in fragment order (lane-linear
-//     16-byte reads); forward uses W, the input-adjoint GEMM uses W^T (second packed copy).
-//   * the weight gradient contracts over columns (points), i.e. across lanes.  Each wave
-//     writes (adjoint, input) B-fragments as rows of a small [column][neuron] LDS image and
-//     reads them back transposed with ds_read_b64_tr_b16 as MFMA operands; gradient tiles
-//     accumulate in registers for the whole kernel.  Vector gradients (biases, w_out, the
-//     2-column first layer) are lane-local running sums, reduced once at the end.
+//     weights when they are packed (k_pack_weights): W for the forward GEMM, W^T for the
+//     input-adjoint GEMM, both in fragment order (lane-linear 16-byte reads).
+//   * the weight gradient contracts over columns (points), i.e. across lanes: (adjoint,
+//     input) B-fragments are read back transposed with ds_read_b64_tr_b16 as MFMA operands;
+//     gradient tiles accumulate in registers for the whole kernel.  Vector gradients (biases,
+//     w_out, the 2-column first layer) are lane-local running sums, reduced once at the end.
+//   * the forward state of BOTH passes of the symmetric double pass stays resident, so the
+//     reverse sweeps (pass B, then pass A) never re-evaluate a pass.
 //   * per-block partials, fixed-order second stage (k_reduce): bitwise reproducible.
 //
+// k_trunk_mfma  ("point-split", 2x64 only, an A/B alternative): a wave owns 16 points and ALL
+//   neurons; activations never leave registers between layers; LDS only for the weights and
+//   the weight-gradient transposes.
+// k_trunk_mfma2 ("neuron-split", every default): SPLIT waves share a 16-point tile, each
+//   owning 16 or 32 neurons; layer outputs and adjoints are exchanged through LDS buffers in
+//   B-fragment order, which double as the transposed-read image of the weight gradient.
+//   Options per shape (M2Cfg): resident blocks per CU, both-pass buffers (KEEP), operand
+//   prefetch (PIPE), fp32 saved state (SVF32), weights streamed through LDS by LDS-DMA
+//   (WSTREAM), split-bf16 operands (X3: hi + lo planes, three MFMAs per product).
+//
 // Precision: bf16 MFMA operands (activations, adjoints, weights), fp32 accumulation and
-// fp32 elementwise math; saved pre-activations are kept as bf16.  Tolerances are stated in
-// tests/test_gpu_parity.py; this path is NOT the 1e-5 parity path.
+// fp32 elementwise math.  Tolerances are stated in tests/test_gpu_parity.py; plain bf16 is
+// NOT the 1e-5 parity path, split-bf16 is.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -1354,10 +1354,10 @@ bool launch2_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, c
         *e = launch2_t<H, L, ACT, NP, MD, SPLIT, WAVES, X3, OCC>(theta, wpk, A, grid, st);   \
         return true;                                                                    \
     }
-    PINN_MCASE2(ACT_SIGMOID, 2, MODE_FWD) PINN_MCASE2(ACT_SIGMOID, 2, MODE_BWD)
-    PINN_MCASE2(ACT_SIGMOID, 1, MODE_FWD) PINN_MCASE2(ACT_SIGMOID, 1, MODE_BWD)
-    PINN_MCASE2(ACT_TANH, 2, MODE_FWD) PINN_MCASE2(ACT_TANH, 2, MODE_BWD)
-    PINN_MCASE2(ACT_TANH, 1, MODE_FWD) PINN_MCASE2(ACT_TANH, 1, MODE_BWD)
+    PINN_MCASE2(ACT_SIGMOID, 2, MODE_FWD) PINN_MCASE2(ACT_SIGMOID, 2, MODE_BWD) PINN_MCASE2(ACT_SIGMOID, 2, MODE_HEAD)
+    PINN_MCASE2(ACT_SIGMOID, 1, MODE_FWD) PINN_MCASE2(ACT_SIGMOID, 1, MODE_BWD) PINN_MCASE2(ACT_SIGMOID, 1, MODE_HEAD)
+    PINN_MCASE2(ACT_TANH, 2, MODE_FWD) PINN_MCASE2(ACT_TANH, 2, MODE_BWD) PINN_MCASE2(ACT_TANH, 2, MODE_HEAD)
+    PINN_MCASE2(ACT_TANH, 1, MODE_FWD) PINN_MCASE2(ACT_TANH, 1, MODE_BWD) PINN_MCASE2(ACT_TANH, 1, MODE_HEAD)
 #undef PINN_MCASE2
     return false;
 }
@@ -1407,7 +1407,7 @@ bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 
 bool mfma_x3_supported(int H, int L) { return (H == 64 || H == 128) && L == 2; }
 
 // A/B switch for measurements (see launch_trunk_mfma): PINN_MFMA_GEN = 0 (default: the fastest
-// measured decomposition), 1..6 = alternatives.
+// measured decomposition), 1..3 = alternatives.
 static int mfma_generation()
 {
     static int gen = -1;
@@ -1423,8 +1423,7 @@ static int mfma_generation()
 int mfma_blocks_per_cu(int H, int L, bool x3)
 {
     const int gen = mfma_generation();
-    if (H == 64 && L == 2 && !x3) return gen == 0 ? 2 : (gen == 5 ? 3 : (gen == 6 ? 4 : 1));
-    if (H == 64 && L == 2 && x3) return gen == 4 ? 2 : 1;
+    if (H == 64 && L == 2 && !x3 && gen == 0) return 2;
     return 1;
 }
 
@@ -1439,7 +1438,7 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
     __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
     // <H, L, SPLIT, WAVES, X3, OCC>: SPLIT waves share a 16-point tile, WAVES per block, OCC
     // resident blocks per CU.  Defaults are the fastest measured decomposition per shape (1M points,
-    // MI355X, kernel ms); PINN_MFMA_GEN = 1..6 selects the alternatives for A/B measurements:
+    // MI355X, kernel ms); PINN_MFMA_GEN = 1..3 selects the alternatives for A/B measurements:
     //   2x64 : <4,4> x 2 blocks/CU 0.72 | point-split gen-1 0.76 | <4,8> 0.74 | <2,8> (spills)
     //   2x128: <8,8> 1.88 | <4,4> 2.7          4x64: <2,4> 2.27 | <4,8> 4.2
     //   4x128: <4,4> 11.8 | <8,8> 15.4  (weights streamed through LDS; both still spill ~0.5 KB/lane:
@@ -1447,7 +1446,6 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
     const int gen = mfma_generation();
     if (x3) {   // split-bf16 operands (3 MFMAs per product): neuron-split kernel only
         if (H == 64 && L == 2) {
-            if (gen == 4) return launch2_HL<64, 2, 4, 4, true, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
             return launch2_HL<64, 2, 4, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
         }
         if (H == 128 && L == 2) {
@@ -1458,11 +1456,9 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
         return false;
     }
     if (H == 64 && L == 2) {
-        if (gen == 1) return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
+        if (gen == 1 && mode != MODE_HEAD) return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
         if (gen == 2) return launch2_HL<64, 2, 2, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
         if (gen == 3) return launch2_HL<64, 2, 4, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
-        if (gen == 5) return launch2_HL<64, 2, 4, 4, false, 3>(act, npass, mode, theta, wpk, A, grid, st, err);
-        if (gen == 6) return launch2_HL<64, 2, 4, 4, false, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
         return launch2_HL<64, 2, 4, 4, false, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
     }
     if (H == 128 && L == 2) {

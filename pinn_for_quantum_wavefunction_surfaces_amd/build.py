@@ -56,5 +56,22 @@ def build_hip(force=False, verbose=False):
     return SO
 
 
+def build_example(force=False, verbose=False):
+    """examples/train_capi.cpp -> examples/train_capi: the C ABI driven from plain C++/HIP."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "train_capi.cpp")
+    exe = os.path.join(root, "examples", "train_capi")
+    if not force and os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(src), os.path.getmtime(SO)):
+        return exe
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "-O2", "--offload-arch=gfx950", "-I" + os.path.join(root, "include"), src,
+           "-L" + HERE, "-lpinn_hip", "-Wl,-rpath,$ORIGIN/../pinn_for_quantum_wavefunction_surfaces_amd", "-o", exe]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return exe
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_example(force=True, verbose=True))

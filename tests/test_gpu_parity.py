@@ -649,6 +649,20 @@ def test_two_ranks_equal_one_rank_with_twice_the_points(tmp_path, golden_dir):
     assert tuple(r0["counts"]) == tuple(tr.counts.cpu().numpy())
 
 
+def test_c_abi_from_plain_cpp_driver():
+    """examples/train_capi.cpp: the library driven through include/pinn.h from C++/HIP alone (its
+    own hipMalloc buffers and stream, no Python, no torch): samples, trains 120 steps at 50 000
+    points and must end with a finite, lower loss (exit code 0)"""
+    import subprocess
+    from pinn_for_quantum_wavefunction_surfaces_amd import build as b
+    exe = b.build_example()                     # no-op when __graft_entry__.build() already made it
+    r = subprocess.run([exe, "50000", "120"], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-600:], r.stderr[-400:])
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-300:])
+    first, last = [float(v) for v in r.stdout.strip().splitlines()[-1].split()[1::2]]
+    assert np.isfinite(last) and last < 0.5 * first
+
+
 # ----------------------------------------------------------------------------- split-bf16 MFMA
 # PINN_PREC_BF16X3: every MFMA operand is hi + lo (two bf16), three MFMAs per product, fp32
 # accumulate, saved pre-activations kept in fp32.  16 operand mantissa bits instead of 8: this is

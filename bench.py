@@ -70,6 +70,9 @@ ARCHS["wide64x3"] = dict(ARCHS["wide64"], precision="bf16x3", dtype="bf16x3",
 ARCHS["wide128x3"] = dict(ARCHS["wide128"], precision="bf16x3", dtype="bf16x3",
                           label="2x128 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
                                 "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
+ARCHS["wide4x64x3"] = dict(ARCHS["wide4x64"], precision="bf16x3", dtype="bf16x3",
+                           label="4x64 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
+                                 "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
 # HBM bytes per launch of each workload's trunk kernel from rocprofv3 PMC passes (FETCH_SIZE x 2 --
 # the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r01zz_final_default_bench.md)
 TRAFFIC = {"wide64": 71.7e6, "wide64x3": 40.1e6, "ref16": 33.2e6, "wide128": 81.4e6}

@@ -1404,7 +1404,7 @@ bool launch_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, co
 }  // namespace
 
 bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
-bool mfma_x3_supported(int H, int L) { return (H == 64 || H == 128) && L == 2; }
+bool mfma_x3_supported(int H, int L) { return ((H == 64 || H == 128) && L == 2) || (H == 64 && L == 4); }
 
 // A/B switch for measurements (see launch_trunk_mfma): PINN_MFMA_GEN = 0 (default: the fastest
 // measured decomposition), 1..3 = alternatives.
@@ -1448,6 +1448,8 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
         if (H == 64 && L == 2) {
             return launch2_HL<64, 2, 4, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
         }
+        if (H == 64 && L == 4)   // deep, fp32-grade: one group per block, hi/lo weight planes from L2
+            return launch2_HL<64, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         if (H == 128 && L == 2) {
             // both passes resident costs 480 B/lane of spills here: 7.0 ms against 5.2 ms
             if (gen == 2) return launch2_HL<128, 2, 8, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);

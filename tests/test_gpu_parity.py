@@ -667,16 +667,16 @@ def test_c_abi_from_plain_cpp_driver():
 # PINN_PREC_BF16X3: every MFMA operand is hi + lo (two bf16), three MFMAs per product, fp32
 # accumulate, saved pre-activations kept in fp32.  16 operand mantissa bits instead of 8: this is
 # the wide path that meets the 1e-5 bar on psi (north_star) while still running on the bf16 pipe.
-@pytest.mark.parametrize("H,tag", [(64, "rand64"), (128, None)])
-def test_mfma_split_bf16_meets_the_fp32_bar(golden_dir, H, tag):
+@pytest.mark.parametrize("H,L,tag", [(64, 2, "rand64"), (128, 2, None), (64, 4, None)])
+def test_mfma_split_bf16_meets_the_fp32_bar(golden_dir, H, L, tag):
     if tag:
         g = np.load(os.path.join(golden_dir, "g2_formA_%s.npz" % tag))   # reference-generated
         theta, x, y, z, R, mask = [g[k] for k in ("theta", "x", "y", "z", "R", "mask")]
     else:
         rng = np.random.default_rng(5)
-        A0 = O.arch(H=H)
+        A0 = O.arch(H=H, L=L)
         off, sz = O.tensor_layout(A0)
-        fan = [2, 2, H, H, H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+        fan = [2, 2] + [H, H] * (L - 1) + [H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
         theta = np.zeros(O.param_count(A0))
         for o, s, fi in zip(off, sz, fan):
             theta[o:o + s] = rng.uniform(-1, 1, s) / np.sqrt(fi)
@@ -685,9 +685,9 @@ def test_mfma_split_bf16_meets_the_fp32_bar(golden_dir, H, tag):
         R = rng.uniform(0.2, 4, n)
         mask = ((np.sqrt((x - R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8)
                 + 2 * (np.sqrt((x + R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8))
-    A, Hm = O.arch(H=H), O.ham_A()
+    A, Hm = O.arch(H=H, L=L), O.ham_A()
     f = pkg.model.FORMULATION_A
-    arch = capi.Arch(H, 2, 32, 10, 0, 2, 1.0, capi.PINN_PREC_BF16X3)
+    arch = capi.Arch(H, L, 32, 10, 0, 2, 1.0, capi.PINN_PREC_BF16X3)
     h = capi.Handle(arch, 0, 4096)
     fw = O.forward(A, Hm, theta, x, y, z, R)
     ref = O.loss_grad(A, Hm, theta, x, y, z, R, mask)

@@ -692,7 +692,7 @@ struct RnetSink {
 // 124 us; 1 wave with lane-local vector sums 225 us -- this kernel alternates short VALU, LDS and
 // matrix-pipe phases and needs the second wave to fill the gaps.
 template <int HE, int HG, int ACT>
-__global__ __launch_bounds__(kBlock, 2) void k_rnet_bwd(const float* __restrict__ th_r,
+__global__ __launch_bounds__(kBlock, HE > 32 ? 1 : 2) void k_rnet_bwd(const float* __restrict__ th_r,
                                                      const float* __restrict__ thT_r,
                                                      const float* __restrict__ R,
                                                      const float* __restrict__ Eb,
@@ -1083,7 +1083,16 @@ static int launch_trunk(const TrunkKey& k, const float* theta, const float* thT,
 }
 
 static bool trunk_supported(int H, int L) { return H == 16 && (L == 2 || L == 3); }
-static bool rnet_supported(int HE, int HG) { return (HE == 32 && HG == 10) || (HE == 16 && HG == 8); }
+// (E-net width, gate width) pairs with a kernel: the reference's (32,10) on the matrix-pipe mat-vec,
+// the rest on the packed-VALU formulation
+#define PINN_RNET_SHAPES(X) X(32, 10) X(16, 8) X(16, 10) X(32, 16) X(64, 10) X(64, 16)
+static bool rnet_supported(int HE, int HG)
+{
+#define PINN_RNET_OK(he, hg) if (HE == he && HG == hg) return true;
+    PINN_RNET_SHAPES(PINN_RNET_OK)
+#undef PINN_RNET_OK
+    return false;
+}
 
 template <int HE, int HG>
 static int launch_rnet_fwd_s(int act, const float* th, const float* thT, const float* R, int64_t n,
@@ -1101,8 +1110,9 @@ static int launch_rnet_fwd(int HE, int HG, int act, const float* th, const float
                            int64_t n, float* E, float* g, float* Eu, int grid, hipStream_t st,
                            hipError_t* e)
 {
-    if (HE == 32 && HG == 10) return launch_rnet_fwd_s<32, 10>(act, th, thT, R, n, E, g, Eu, grid, st, e);
-    if (HE == 16 && HG == 8) return launch_rnet_fwd_s<16, 8>(act, th, thT, R, n, E, g, Eu, grid, st, e);
+#define PINN_RNET_FWD(he, hg) if (HE == he && HG == hg) return launch_rnet_fwd_s<he, hg>(act, th, thT, R, n, E, g, Eu, grid, st, e);
+    PINN_RNET_SHAPES(PINN_RNET_FWD)
+#undef PINN_RNET_FWD
     return 0;
 }
 
@@ -1124,8 +1134,9 @@ static int launch_rnet_bwd(int HE, int HG, int act, const float* th, const float
                            const float* gb, int64_t n, float* part, int stride, int grid,
                            hipStream_t st, hipError_t* e)
 {
-    if (HE == 32 && HG == 10) return launch_rnet_bwd_s<32, 10>(act, th, thT, R, Eb, gb, n, part, stride, grid, st, e);
-    if (HE == 16 && HG == 8) return launch_rnet_bwd_s<16, 8>(act, th, thT, R, Eb, gb, n, part, stride, grid, st, e);
+#define PINN_RNET_BWD(he, hg) if (HE == he && HG == hg) return launch_rnet_bwd_s<he, hg>(act, th, thT, R, Eb, gb, n, part, stride, grid, st, e);
+    PINN_RNET_SHAPES(PINN_RNET_BWD)
+#undef PINN_RNET_BWD
     return 0;
 }
 

@@ -922,7 +922,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     act012v<ACT>(a[tt][0], s0, s1, s2);
                     const f32x4 q = a[tt][1] * a[tt][1] + a[tt][2] * a[tt][2] + a[tt][3] * a[tt][3];
                     const f32x4 ol = s1 * a[tt][4] + s2 * q;
-                    if (SVF) {
+                    if constexpr (SVF) {
                         svf[SL][l - 1][tt][0] = s0;
 #pragma unroll
                         for (int s = 1; s < 5; s++) svf[SL][l - 1][tt][s] = a[tt][s];
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
                     f32x4 h, a[5];
-                    if (SVF) {
+                    if constexpr (SVF) {
                         h = svf[SL][NW - 1][tt][0];
 #pragma unroll
                         for (int s = 1; s < 5; s++) a[s] = svf[SL][NW - 1][tt][s];
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
 #pragma unroll
                         for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
                         h = h0[SL][tt];
-                    } else if (SVF) {
+                    } else if constexpr (SVF) {
                         h = svf[SL][l - 2][tt][0];
 #pragma unroll
                         for (int s = 1; s < 5; s++) a[s] = svf[SL][l - 2][tt][s];

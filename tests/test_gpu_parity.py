@@ -124,6 +124,33 @@ def test_three_layer_tanh_small_Rnet_matches_oracle():
     assert rel(out[:h.P], ref["grad"]) < 1e-4
 
 
+@pytest.mark.parametrize("HE,HG,act", [(16, 10, 0), (32, 16, 1), (64, 10, 1), (64, 16, 0)])
+def test_other_Rnet_widths_match_oracle(HE, HG, act):
+    """E-net / gate widths beyond the reference's (32, 10): same kernels (packed-VALU mat-vecs),
+    oracle only -- the reference fixes these widths"""
+    A = O.arch(HE=HE, HG=HG, act=act)
+    rng = np.random.default_rng(HE + HG)
+    off, sz = O.tensor_layout(A)
+    theta = np.zeros(O.param_count(A))
+    fan = [2, 2, 16, 16, 16, 16, 1, 1, HE, HE, HE, HE, 1, 1, HG, HG]
+    for o, s_, fi in zip(off, sz, fan):
+        theta[o:o + s_] = rng.uniform(-1, 1, s_) / np.sqrt(fi)
+    n = 1500
+    x, y, z = rng.uniform(-18, 18, (3, n))
+    R = rng.uniform(0.2, 4, n)
+    mask = ((np.sqrt((x - R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8)
+            + 2 * (np.sqrt((x + R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8))
+    arch, f = make(dict(HE=HE, HG=HG, act=act))
+    h = capi.Handle(arch, 0, 4096)
+    fw = O.forward(A, O.ham_A(), theta, x, y, z, R)
+    ref = O.loss_grad(A, O.ham_A(), theta, x, y, z, R, mask)
+    psi, E, lap, res = run_forward(h, f, theta, x, y, z, R)
+    out = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    assert rel(psi, fw["psi"]) < 1e-5 and rel(E, fw["E"]) < 1e-5 and rel(res, fw["res"]) < 2e-5
+    assert abs(out[h.P:].sum() / ref["Ltot"] - 1) < 1e-4
+    assert rel(out[:h.P], ref["grad"]) < 1e-4
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 1000])
 def test_ragged_sizes(golden_dir, n):
     g = np.load(os.path.join(golden_dir, "g2_formA_ionHsym.npz"))
@@ -257,7 +284,7 @@ def test_module_surface_on_gpu(golden_dir, tmp_path):
         Ltot, Lpde, Lbc, Eo = model.LossFunctions(x, y, z, R, params, b1, b2)
         Ltot.backward()
         grads = np.concatenate([p.grad.cpu().numpy().ravel() for p in model.parameters()])
-        assert abs(float(Ltot) / g["Ltot"] - 1) < 1e-4
+        assert abs(float(Ltot.detach()) / g["Ltot"] - 1) < 1e-4
         assert abs(float(Lbc) - g["Lbc"]) < 1e-4 * g["Ltot"] + 2e-3 * g["Lbc"]
         assert rel(grads, g["grad"]) < 1e-4
         assert rel(Eo.cpu().numpy()[:, 0], g["E"]) < 1e-5

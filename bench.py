@@ -70,6 +70,10 @@ ARCHS["wide64x3"] = dict(ARCHS["wide64"], precision="bf16x3", dtype="bf16x3",
 ARCHS["wide128x3"] = dict(ARCHS["wide128"], precision="bf16x3", dtype="bf16x3",
                           label="2x128 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
                                 "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
+ARCHS["mid32"] = dict(H=32, L=2, HE=16, HG=8, act=0, n_pass=2, out_scale=1.0, precision="f32",
+                      act_name="sigmoid", peak=157.3, dtype="f32",
+                      label="2x32 trunk + 2x16 E-net + 1x8 gate, sigmoid, fp32 (the 32-wide instantiation of "
+                            "the packed-VALU trunk: functional, not tuned), seeded random init")
 ARCHS["wide4x64x3"] = dict(ARCHS["wide4x64"], precision="bf16x3", dtype="bf16x3",
                            label="4x64 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
                                  "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")

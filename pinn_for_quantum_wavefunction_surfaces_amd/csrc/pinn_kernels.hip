@@ -1079,10 +1079,11 @@ static int launch_trunk(const TrunkKey& k, const float* theta, const float* thT,
 {
     if (k.H == 16 && k.L == 2) return launch_trunk_HL<16, 2>(k, theta, thT, A, grid, st, e);
     if (k.H == 16 && k.L == 3) return launch_trunk_HL<16, 3>(k, theta, thT, A, grid, st, e);
+    if (k.H == 32 && k.L == 2) return launch_trunk_HL<32, 2>(k, theta, thT, A, grid, st, e);
     return 0;
 }
 
-static bool trunk_supported(int H, int L) { return H == 16 && (L == 2 || L == 3); }
+static bool trunk_supported(int H, int L) { return (H == 16 && (L == 2 || L == 3)) || (H == 32 && L == 2); }
 // (E-net width, gate width) pairs with a kernel: the reference's (32,10) on the matrix-pipe mat-vec,
 // the rest on the packed-VALU formulation
 #define PINN_RNET_SHAPES(X) X(32, 10) X(16, 8) X(16, 10) X(32, 16) X(64, 10) X(64, 16)

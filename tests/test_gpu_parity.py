@@ -124,6 +124,20 @@ def test_three_layer_tanh_small_Rnet_matches_oracle():
     assert rel(out[:h.P], ref["grad"]) < 1e-4
 
 
+def test_fp32_trunk_width_32_matches_reference(golden_dir):
+    """NN_ion(params, 32, 16, 8): golden vector generated by the reference itself (g2 rand32), on the
+    fp32 parity path (the 32-wide instantiation of the packed-VALU trunk; functional, not tuned)"""
+    g = np.load(os.path.join(golden_dir, "g2_formA_rand32.npz"))
+    arch, f = make(dict(H=32, HE=16, HG=8))
+    h = capi.Handle(arch, 0, 4096)
+    psi, E, lap, res = run_forward(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"])
+    assert rel(psi, g["psi"]) < 1e-5 and rel(E, g["E"]) < 1e-5
+    assert rel(lap, g["lap"]) < 1e-5 and rel(res, g["res"]) < 2e-5
+    out = run_loss_grad(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"], g["mask"])
+    assert abs(out[h.P:].sum() / g["Ltot"] - 1) < 1e-4
+    assert rel(out[:h.P], g["grad"]) < 1e-4
+
+
 @pytest.mark.parametrize("HE,HG,act", [(16, 10, 0), (32, 16, 1), (64, 10, 1), (64, 16, 0)])
 def test_other_Rnet_widths_match_oracle(HE, HG, act):
     """E-net / gate widths beyond the reference's (32, 10): same kernels (packed-VALU mat-vecs),

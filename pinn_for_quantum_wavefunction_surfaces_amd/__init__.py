@@ -3,7 +3,7 @@
 Host side mirrors the reference's Python surface (poc/main.py, train.py); the
 compute is the HIP library behind include/pinn.h.
 """
-from . import capi, formats  # noqa: F401
+from . import capi, flat, formats  # noqa: F401
 from .analysis import (calculate_E_R, dEdR_int, energy_from_psi, energy_from_psi_LCAO,  # noqa: F401
                        force_curves, psi_cut)
 from .capi import PinnError  # noqa: F401

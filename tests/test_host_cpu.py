@@ -131,6 +131,26 @@ def test_pt_and_model_bin_convert_both_ways(tmp_path, golden_dir):
         torch.set_default_dtype(torch.float32)
 
 
+def test_flat_script_surface_matches_train_py_init_and_writer(tmp_path, golden_dir):
+    """flat.init_params under train.py's seed reproduces the tensors train.py's own `ini` calls
+    produced (g3 was generated by executing them); flat.write_model_bin writes what
+    formats.write_model_bin writes for the equivalent state_dict"""
+    from pinn_for_quantum_wavefunction_surfaces_amd import flat
+    g = np.load(os.path.join(golden_dir, "g3_formB.npz"))
+    torch.manual_seed(12345)                              # train.py:75
+    params = flat.init_params()
+    assert [tuple(t.shape) for t in params][:6] == [(2, 16), (16,), (16, 16), (16,), (16, 1), (1,)]
+    sd = formats.bin_arrays_to_state_dict([t.detach().numpy() for t in params])
+    theta = np.concatenate([sd[k + s].ravel() for k in formats.STATE_ORDER for s in (".weight", ".bias")])
+    assert np.array_equal(theta, g["theta"])
+    a, b = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    flat.write_model_bin(a, params)
+    formats.write_model_bin(b, sd)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    with pytest.raises(capi.PinnError):                   # the loop itself is GPU only
+        flat.train(params, lr=8e-3, epochs=1, device="cpu")
+
+
 def test_no_cpu_fallback():
     m = pkg.NN_ion(pkg.set_params())
     x = torch.zeros(8, 1)

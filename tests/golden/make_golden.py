@@ -36,7 +36,7 @@ import numpy as np
 import torch
 
 REF = os.environ.get("PINN_REFERENCE", "/root/reference")
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("PINN_GOLDEN_OUT", os.path.dirname(os.path.abspath(__file__)))
 
 STATE_KEYS = ["Lin_H1", "Lin_H2", "Lin_out", "Lin_E1", "Lin_E2", "Lin_Eout", "netDecayL",
               "netDecay"]

@@ -187,3 +187,25 @@ def test_extension_tanh_multilayer_gradcheck():
         fm = O.forward(A, Hm, theta, x - dx, y - dy, z - dz, R)["psi"]
         lap += (fp - 2 * f0["psi"] + fm) / h ** 2
     assert np.max(np.abs(lap - f0["lap"])) < 1e-5 * max(1.0, np.max(np.abs(f0["lap"])))
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("PINN_REFERENCE", "/root/reference")),
+                    reason="the reference tree only exists in the build container")
+def test_committed_fixtures_regenerate_bit_identically(tmp_path, golden_dir):
+    """run tests/golden/make_golden.py (which executes the reference's own code) into a scratch
+    directory: every array of every committed fixture comes out bit-identical"""
+    import glob
+    import subprocess
+    import sys
+    import shutil
+    shutil.copy(os.path.join(golden_dir, "g6_modelbin.npz"), tmp_path)   # g7 reads g6's blob
+    env = dict(os.environ, PINN_GOLDEN_OUT=str(tmp_path), MPLBACKEND="Agg")
+    subprocess.run([sys.executable, os.path.join(golden_dir, "make_golden.py")], check=True, env=env,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    files = sorted(glob.glob(os.path.join(golden_dir, "*.npz")))
+    assert len(files) >= 12
+    for f in files:
+        a, b = np.load(f), np.load(os.path.join(str(tmp_path), os.path.basename(f)))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (os.path.basename(f), k)

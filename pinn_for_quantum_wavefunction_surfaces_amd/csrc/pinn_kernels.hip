@@ -852,7 +852,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
-__global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t step0,
+constexpr int kSampleBlock = 1024;   // few, large blocks: the two count atomics per block hit one address
+__global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t step0,
                                                    const int32_t* __restrict__ step_dev, int64_t first,
                                                    int64_t n, float box, float Rlo, float Rhi,
                                                    float cutoff, float bc_cutoff,
@@ -865,8 +866,8 @@ __global__ __launch_bounds__(kBlock) void k_sample(uint64_t seed, uint64_t step0
     const float two_box = box + box, dR = Rhi - Rlo;
     const float cut2 = cutoff * cutoff, bc2 = bc_cutoff * bc_cutoff;
     unsigned c1 = 0, c2 = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * kBlock) {
+    for (int64_t i = (int64_t)blockIdx.x * kSampleBlock + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kSampleBlock) {
         const uint64_t gi = (uint64_t)(first + i);
         uint32_t o[4];
         philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)step, (uint32_t)(step >> 32),
@@ -1418,7 +1419,8 @@ extern "C" int pinn_sample(pinn_handle* h, uint64_t seed, uint64_t step, const i
     if (!x || !y || !z || !R || n < 1 || first < 0) return fail(h, PINN_ERR_ARG, "null pointer or bad range");
     hipStream_t st = (hipStream_t)stream;
     if (counts) HIPCHK(h, hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), st));
-    hipLaunchKernelGGL(k_sample, dim3(grid_for(n, 512)), dim3(kBlock), 0, st, seed, step, step_dev, first, n,
+    const int64_t sblocks = (n + kSampleBlock - 1) / kSampleBlock;
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)(sblocks < 256 ? sblocks : 256)), dim3(kSampleBlock), 0, st, seed, step, step_dev, first, n,
                        box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
                        (unsigned long long*)counts);
     hipError_t e = hipGetLastError();

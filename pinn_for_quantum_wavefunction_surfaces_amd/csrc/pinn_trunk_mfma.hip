@@ -632,7 +632,9 @@ struct M2Cfg {
     // WSTREAM (bf16 only): one layer matrix at a time, double-buffered in LDS by LDS-DMA
     // (global_load_lds_dwordx4) while the previous layer computes; the packed set stays in L2
     static constexpr bool WSTREAM = !WLDS && !X3;
-    static constexpr int WPK = WLDS ? WPK_ALL : (WSTREAM ? 2 * H * H : 0);
+    // split-bf16 whose two planes do not fit: the hi plane sits in LDS, the lo plane is read from L2
+    static constexpr bool WHI = X3 && !WLDS && (size_t)(WPK_ALL / 2) * 2 <= 64 * 1024;
+    static constexpr int WPK = WLDS ? WPK_ALL : (WSTREAM ? 2 * H * H : (WHI ? WPK_ALL / 2 : 0));
     // deep wide trunks keep the k loop rolled: unrolled, the scheduler hoists all 20 B-fragment
     // reads of a layer and the kernel spills
     static constexpr int KCU = (L > 2 && H >= 128) ? 1 : KC;
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
     };
 
     {
-        if (C::WLDS) {
+        if (C::WLDS || C::WHI) {
             const uint4* src = reinterpret_cast<const uint4*>(wpk_g);
             uint4* dst = reinterpret_cast<uint4*>(wpk);
             for (int k = threadIdx.x; k < C::WPK / 8; k += NT) dst[k] = src[k];
@@ -745,7 +747,9 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
         for (int k = threadIdx.x; k < C::ZBYTES / 4; k += NT)
             reinterpret_cast<unsigned*>(lds_raw + C::OFF_ZERO)[k] = 0u;
     }
-    const __bf16* wsrc = C::WLDS ? wpk : wpk_g;   // one provenance per instantiation
+    const __bf16* wsrc = (C::WLDS || C::WHI) ? wpk : wpk_g;   // one provenance per instantiation
+    // lo plane: behind the hi plane in the same image, or (WHI) in global memory
+    const __bf16* wlo_f = C::WHI ? wpk_g + WPLANE : wsrc + WPLANE;
     // ---- weight streaming: matrix use k reads LDS buffer k & 1; at the start of use k every wave
     // copies its share of use k+1's matrix into the other buffer (free since the barrier that ended
     // use k-1); the barrier that ends use k drains the copy (vmcnt(0)) before anyone reads it.
@@ -903,7 +907,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     for (int tt = 0; tt < RT; tt++) {
                         const __bf16* pw = wf + (((RT * part + tt) * KC + kc) * 64 + lane) * 8;
                         wa[tt] = *reinterpret_cast<const bf16x8*>(pw);
-                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(pw + WPLANE) : wa[tt];
+                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(wlo_f + (pw - wsrc)) : wa[tt];
                     }
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
@@ -1087,7 +1091,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     for (int tt = 0; tt < RT; tt++) {
                         const __bf16* pwb = wb + (((RT * part + tt) * KC + kc) * 64 + lane) * 8;
                         wa[tt] = *reinterpret_cast<const bf16x8*>(pwb);
-                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(pwb + WPLANE) : wa[tt];
+                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(wlo_f + (pwb - wsrc)) : wa[tt];
                     }
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
@@ -1448,11 +1452,10 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
         if (H == 64 && L == 2) {
             return launch2_HL<64, 2, 4, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
         }
-        if (H == 64 && L == 4)   // deep, fp32-grade: one group per block, hi/lo weight planes from L2
+        if (H == 64 && L == 4)   // deep, fp32-grade: one group per block, hi plane in LDS, lo plane from L2
             return launch2_HL<64, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         if (H == 128 && L == 2) {
-            // both passes resident costs 480 B/lane of spills here: 7.0 ms against 5.2 ms
-            if (gen == 2) return launch2_HL<128, 2, 8, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
+            // hi weight plane in LDS (64 KB), lo plane from L2, one pass resident: 4.3 ms
             return launch2_HL<128, 2, 8, 8, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         }
         return false;

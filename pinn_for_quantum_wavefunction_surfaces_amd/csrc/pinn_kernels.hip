@@ -9,6 +9,7 @@
 //   k_rnet_bwd        reverse pass of the R-only sub-nets from per-point dL/dE, dL/dg
 //   k_reduce          fixed-order second-stage reduction of per-block partials (deterministic)
 //   k_adam        K4  Adam + best-so-far snapshot (train.py:23,58-60,72)
+//   k_energy_R        E, dE/dR, d2E/dR2 of the E-net (the force curves, poc/main.py:1316-1328)
 //
 // Execution shape: one collocation point per lane (wave64).  Weights are read with wave-uniform
 // addresses, so hipcc keeps them in SGPRs (s_load through the scalar cache); every mat-vec is a
@@ -422,7 +423,7 @@ struct Mat32 {
 
 // v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b.  Inline asm on purpose: hipcc
 // (ROCm 7.2) lowers the SECOND result of __builtin_amdgcn_permlane32_swap to the same register as
-// the first (checked on hardware with gpurun_scratch-style integer tests).  The s_nops are the
+// the first (checked on hardware with a stand-alone integer test).  The s_nops are the
 // VALU-write -> permlane-read and permlane-write -> MFMA-read wait states, which the compiler does
 // not pad inside an asm statement.
 __device__ __forceinline__ void swap32(float& a, float& b)

@@ -33,3 +33,10 @@ bool mfma_x3_supported(int H, int L);
 bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, const float* theta,
                        void* packed_weights, const TrunkArgs& A, int grid, hipStream_t st,
                        hipError_t* err);
+
+// ---- R-only nets on the matrix pipe (pinn_trunk_mfma.hip): (HE, HG) = (32, 10), split-bf16 operands
+bool rnet_mfma_supported(int HE, int HG);
+hipError_t launch_rnet_mfma_fwd(int act, const float* thE, const float* R, int64_t n, float* E, float* g,
+                                float* Eu, int grid, hipStream_t st);
+hipError_t launch_rnet_mfma_bwd(int act, const float* thE, const float* R, const float* Eb, const float* gb,
+                                int64_t n, float* part, int stride, int grid, hipStream_t st);

@@ -1145,6 +1145,32 @@ static int launch_rnet_bwd(int HE, int HG, int act, const float* th, const float
 
 }  // namespace
 
+static int grid_for(int64_t n, int cap)
+{
+    const int64_t tiles = (n + kBlock - 1) / kBlock;
+    return (int)(tiles < cap ? tiles : cap);
+}
+
+// grid of the 16-points-per-wave R-net kernels: one block = 64 points per trip
+static int grid16(int64_t n, int cap)
+{
+    const int64_t b = (n + 63) / 64;
+    return (int)(b < cap ? b : cap);
+}
+
+// E(R), g(R) for the batch: matrix-pipe kernel for the reference widths, lane = point kernels otherwise
+static int rnet_forward(pinn_handle* h, const float* theta, const float* R, int64_t n, float* Eu,
+                        hipStream_t st, hipError_t* e)
+{
+    const pinn_arch& a = h->arch;
+    if (rnet_mfma_supported(a.HE, a.HG)) {
+        *e = launch_rnet_mfma_fwd(a.act, theta + h->PT, R, n, h->E, h->g, Eu, grid16(n, h->nbR * 2), st);
+        return 1;
+    }
+    return launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, n, h->E, h->g, Eu,
+                           grid_for(n, h->nbR * 4), st, e);
+}
+
 static hipError_t prep_theta(pinn_handle* h, const float* theta, hipStream_t st)
 {
     const pinn_arch& a = h->arch;
@@ -1300,12 +1326,6 @@ static int check_common(pinn_handle* h, const void* theta, const void* x, const 
     return PINN_OK;
 }
 
-static int grid_for(int64_t n, int cap)
-{
-    const int64_t tiles = (n + kBlock - 1) / kBlock;
-    return (int)(tiles < cap ? tiles : cap);
-}
-
 extern "C" int pinn_energy_R(pinn_handle* h, const float* theta, const float* R, int64_t n,
                              float* E, float* dE, float* d2E, void* stream)
 {
@@ -1337,7 +1357,7 @@ extern "C" int pinn_forward(pinn_handle* h, const float* theta, const float* x, 
     const pinn_arch& a = h->arch;
     e = prep_theta(h, theta, st);
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_prep_theta", e);
-    if (!launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, n, h->E, h->g, E, grid_for(n, h->nbR * 4), st, &e))
+    if (!rnet_forward(h, theta, R, n, E, st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_fwd", e);
     if (!psi && !lap && !res) return PINN_OK;
@@ -1364,10 +1384,11 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     const pinn_arch& a = h->arch;
-    const int gT = grid_for(n, h->nbT), gR = grid_for(n, h->nbR);
+    const bool rmfma = rnet_mfma_supported(a.HE, a.HG);
+    const int gT = grid_for(n, h->nbT), gR = rmfma ? grid16(n, h->nbR) : grid_for(n, h->nbR);
     e = prep_theta(h, theta, st);
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_prep_theta", e);
-    if (!launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, n, h->E, h->g, nullptr, grid_for(n, h->nbR * 4), st, &e))
+    if (!rnet_forward(h, theta, R, n, nullptr, st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_fwd", e);
     TrunkArgs A{};
@@ -1386,7 +1407,9 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
         HIPCHK(h, hipEventRecord(h->ev[2 * slot + 1], st));
         h->prof_calls++;
     }
-    if (!launch_rnet_bwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st, &e))
+    if (rmfma)
+        e = launch_rnet_mfma_bwd(a.act, theta + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st);
+    else if (!launch_rnet_bwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_bwd", e);
     const int tot = h->P + 3;

@@ -40,8 +40,8 @@ def total_flops_per_point(H, L, HE, HG, n_pass):
 ARCHS = {
     "ref16": dict(H=16, L=2, HE=32, HG=10, act=0, n_pass=2, out_scale=1.0, precision="f32",
                   act_name="sigmoid", peak=157.3, dtype="f32",
-                  label="reference arch 2x16 trunk + 2x32 E-net + 1x10 gate, sigmoid, fp32 "
-                        "(VALU + f32 MFMA), ionHsym weights"),
+                  label="reference arch 2x16 trunk + 2x32 E-net + 1x10 gate, sigmoid, fp32 trunk "
+                        "(VALU + f32 MFMA; E-net 32x32 layer: split-bf16 MFMA), ionHsym weights"),
     "wide64": dict(H=64, L=2, HE=32, HG=10, act=1, n_pass=2, out_scale=1.0, precision="bf16",
                    act_name="tanh", peak=2500.0, dtype="bf16",
                    label="2x64 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "

@@ -37,7 +37,9 @@ typedef enum pinn_status {
 
 enum { PINN_ACT_SIGMOID = 0, PINN_ACT_TANH = 1 };
 enum {
-    PINN_PREC_F32 = 0,    /* fp32 VALU + exact f32 MFMA: the parity path */
+    PINN_PREC_F32 = 0,    /* fp32 trunk (VALU + exact f32 MFMA): the parity path.  On every setting the
+                             32x32 layer of the E-net runs on the bf16 pipe with split operands (three
+                             pieces = 24 bits in the forward; PINN_RNET_MFMA=0 selects exact fp32) */
     PINN_PREC_BF16 = 1,   /* bf16 MFMA operands, fp32 accumulate and elementwise */
     PINN_PREC_BF16X3 = 2  /* split-bf16 (hi/lo, 3 products), fp32 accumulate */
 };

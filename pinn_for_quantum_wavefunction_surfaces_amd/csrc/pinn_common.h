@@ -40,3 +40,9 @@ hipError_t launch_rnet_mfma_fwd(int act, const float* thE, const float* R, int64
                                 float* Eu, int grid, hipStream_t st);
 hipError_t launch_rnet_mfma_bwd(int act, const float* thE, const float* R, const float* Eb, const float* gb,
                                 int64_t n, float* part, int stride, int grid, hipStream_t st);
+
+// ---- the 16-wide reference trunk on the matrix pipe (pinn_trunk_mfma.hip, k_trunk16): two blocks per CU,
+// 64 points per block and trip
+bool trunk16_mfma_supported(int H, int L);
+hipError_t launch_trunk16_mfma(int act, int npass, int mode, const float* theta, const TrunkArgs& A, int grid,
+                               hipStream_t st);

@@ -1179,11 +1179,23 @@ static hipError_t prep_theta(pinn_handle* h, const float* theta, hipStream_t st)
     return hipGetLastError();
 }
 
+// persistent grid of the trunk kernel for n points (also the number of partial rows k_reduce sums)
+static int trunk_grid(const pinn_handle* h, int64_t n)
+{
+    const pinn_arch& a = h->arch;
+    if (a.precision == PINN_PREC_F32 && trunk16_mfma_supported(a.H, a.L)) return grid16(n, h->nbT);
+    return grid_for(n, h->nbT);
+}
+
 static int run_trunk(pinn_handle* h, int mode, const float* theta, const TrunkArgs& A, int grid,
                      hipStream_t st, hipError_t* e)
 {
     const pinn_arch& a = h->arch;
     if (a.precision == PINN_PREC_F32) {
+        if (trunk16_mfma_supported(a.H, a.L)) {   // the reference trunk on the matrix pipe (k_trunk16)
+            *e = launch_trunk16_mfma(a.act, a.n_pass, mode, theta, A, grid, st);
+            return 1;
+        }
         const TrunkKey k{a.H, a.L, a.act, a.n_pass, mode};
         return launch_trunk(k, theta, h->thT, A, grid, st, e);
     }
@@ -1223,7 +1235,8 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     const int64_t tiles = (max_points + kBlock - 1) / kBlock;
     // one resident 4-wave block per CU for both trunk kernels (1 wave per SIMD)
     const int bpc = arch->precision != PINN_PREC_F32
-                        ? mfma_blocks_per_cu(arch->H, arch->L, arch->precision == PINN_PREC_BF16X3) : 1;
+                        ? mfma_blocks_per_cu(arch->H, arch->L, arch->precision == PINN_PREC_BF16X3)
+                        : (trunk16_mfma_supported(arch->H, arch->L) ? 2 : 1);
     h->nbT = (int)(tiles < (int64_t)cus * bpc ? tiles : (int64_t)cus * bpc);
     h->nbR = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
     h->strideT = h->PT + 3;
@@ -1366,7 +1379,7 @@ extern "C" int pinn_forward(pinn_handle* h, const float* theta, const float* x, 
     A.n = n; A.a = ham->a; A.b = ham->b; A.c = ham->c; A.P = ham->P; A.out_scale = a.out_scale;
     A.invN = 0.f; A.invN1 = 0.f; A.invN2 = 0.f;
     A.psi = psi; A.lap = lap; A.res = res;
-    if (!run_trunk(h, MODE_FWD, theta, A, grid_for(n, h->nbT), st, &e))
+    if (!run_trunk(h, MODE_FWD, theta, A, trunk_grid(h, n), st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L, precision)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_trunk<FWD>", e);
     return PINN_OK;
@@ -1385,7 +1398,7 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     hipError_t e = hipSuccess;
     const pinn_arch& a = h->arch;
     const bool rmfma = rnet_mfma_supported(a.HE, a.HG);
-    const int gT = grid_for(n, h->nbT), gR = rmfma ? grid16(n, h->nbR) : grid_for(n, h->nbR);
+    const int gT = trunk_grid(h, n), gR = rmfma ? grid16(n, h->nbR) : grid_for(n, h->nbR);
     e = prep_theta(h, theta, st);
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_prep_theta", e);
     if (!rnet_forward(h, theta, R, n, nullptr, st, &e))

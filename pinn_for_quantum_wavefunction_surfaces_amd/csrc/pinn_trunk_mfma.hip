@@ -1747,6 +1747,312 @@ __global__ __launch_bounds__(kBlock, 2) void k_rnet_mfma_bwd(const float* __rest
     for (int k = threadIdx.x; k < PR; k += kBlock) out[k] = gimg[k];
 }
 
+
+// =====================================================================================
+// The reference's own trunk (H = 16, two hidden layers) on the matrix pipe: k_trunk16.
+// One wave owns a 16-point tile and all 16 neurons; lane (g, c) holds neurons 4g + r of point c,
+// five streams of them, so the whole per-point algebra is lane-local and the 16 x 16 layer is
+// v_mfma_f32_16x16x16_bf16: the lane's 4 values ARE its B-operand k-slots (no permutation at
+// K = 16) and nothing leaves registers between layers.  Operands are split bf16 with fp32
+// accumulation: THREE pieces (24 mantissa bits, six MFMAs per product) in the forward sweep --
+// this is the 1e-5 parity architecture -- and two pieces (three MFMAs) in the reverse sweep's
+// adjoint GEMM and weight gradient (gradient bar 1e-4).  The weight gradient contracts over the
+// 80 (stream, point) columns with transposed reads of a per-wave LDS image, as everywhere in this
+// file.  Both passes of the symmetric double pass keep their forward state (no recompute).
+// Against k_trunk of pinn_kernels.hip (lane = point, mat-vecs as packed VALU rank-1 updates): the
+// 16 x 16 mat-vecs were 77 % of that kernel's VALU instructions.
+__device__ __forceinline__ s16x4 as_s4(u32x2 v) { return __builtin_bit_cast(s16x4, v); }
+
+__device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
+template <int ACT, int NPASS, int MODE>
+__global__ __launch_bounds__(kBlock, 2) void k_trunk16(const float* __restrict__ theta, TrunkArgs A)
+{
+    using Lay = TrunkLayout<16, 2>;
+    constexpr int PT = Lay::size;
+    constexpr int PITCH = 24;                 // bf16 per image row: 16 neurons + 8
+    constexpr int IMG = 5 * 16 * PITCH;       // one image: 5 streams x 16 points
+    __shared__ __attribute__((aligned(16))) __bf16 imgs[(MODE == MODE_BWD ? kWavesPerBlock * 4 * IMG : 8)];
+    __shared__ float gimg[PT + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    __bf16* Yh = imgs + (MODE == MODE_BWD ? (size_t)wave * 4 * IMG : 0);
+    __bf16* Yl = Yh + IMG;
+    __bf16* Xh = Yl + IMG;
+    __bf16* Xl = Xh + IMG;
+
+    // ---- per-lane constants: the own neurons' first-layer rows, biases, output weights
+    f32x4 w0a, w0b, b0, b1, wo;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int nj = 4 * g + r;
+        w0a[r] = theta[Lay::W(0) + 2 * nj];
+        w0b[r] = theta[Lay::W(0) + 2 * nj + 1];
+        b0[r] = theta[Lay::b(0) + nj];
+        b1[r] = theta[Lay::b(1) + nj];
+        wo[r] = theta[Lay::Wout + nj];
+    }
+    const float bout = theta[Lay::bout];
+    // A fragments of the 16 x 16 layer: forward W1[c][4g + j] in three pieces, reverse W1[4g + j][c] in two
+    s16x4 Fh, Fm, Fl, Th, Tl;
+    {
+        u32x2 fh, fm, fl, th, tl;
+        f32x4 wf, wt;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            wf[j] = theta[Lay::W(1) + c * 16 + 4 * g + j];
+            wt[j] = theta[Lay::W(1) + (4 * g + j) * 16 + c];
+        }
+        split4x3(wf, fh, fm, fl);
+        split4(wt, th, tl);
+        Fh = as_s4(fh); Fm = as_s4(fm); Fl = as_s4(fl); Th = as_s4(th); Tl = as_s4(tl);
+    }
+
+    f32x4 wacc = splat(0.f), bacc0 = splat(0.f), bacc1 = splat(0.f), w0acc0 = splat(0.f), w0acc1 = splat(0.f),
+          woacc = splat(0.f);
+    float acc_bout = 0.f, acc_pde = 0.f, acc_bc1 = 0.f, acc_bc2 = 0.f;
+    float invN1 = A.invN1, invN2 = A.invN2;
+    if (MODE != MODE_FWD && A.bc_counts) {
+        const long long c1 = A.bc_counts[0], c2 = A.bc_counts[1];
+        invN1 = c1 > 0 ? 1.0f / (float)c1 : 0.0f;
+        invN2 = c2 > 0 ? 1.0f / (float)c2 : 0.0f;
+    }
+    const float lead = g == 0 ? 1.0f : 0.0f;
+    const int64_t ntile = (A.n + 15) / 16;
+
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntile;
+         tile += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t idx = tile * 16 + c;
+        const bool valid = idx < A.n;
+        const int64_t id = valid ? idx : A.n - 1;
+        const float xv = A.x[id], yv = A.y[id], zv = A.z[id], Rv = A.R[id];
+        const float Ev = A.E[id], gv = A.g[id];
+        float m1 = 0.f, m2 = 0.f;
+        if (MODE != MODE_FWD && A.mask) {
+            const uint8_t mk = A.mask[id];
+            m1 = float(mk & 1);
+            m2 = float((mk >> 1) & 1);
+        }
+        float inA[2][5], ri1, ri2;
+        orbital<float>(xv - Rv, yv, zv, inA[0], ri1);
+        orbital<float>(xv + Rv, yv, zv, inA[1], ri2);
+        const float F = inA[0][0] + A.P * inA[1][0];
+        const float lapF = inA[0][4] + A.P * inA[1][4];
+
+        // saved forward state per pass: layer-0 output streams (the X operand of the weight
+        // gradient; stream 0 is the layer-0 activation) and (h, a_x, a_y, a_z, a_lap) of layer 1
+        f32x4 ox[NPASS][5], sv[NPASS][5];
+        float SvT = 0.f, SlT = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ps++) {
+            const bool useB = ps == 1;
+            float in[2][5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                in[0][s] = useB ? inA[1][s] : inA[0][s];
+                in[1][s] = useB ? inA[0][s] : inA[1][s];
+            }
+            f32x4 a0[5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
+            a0[0] += b0;
+            {
+                f32x4 s0, s1, s2;
+                act012v<ACT>(a0[0], s0, s1, s2);
+                const f32x4 q = a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3];
+                ox[ps][0] = s0;
+                ox[ps][1] = s1 * a0[1];
+                ox[ps][2] = s1 * a0[2];
+                ox[ps][3] = s1 * a0[3];
+                ox[ps][4] = s1 * a0[4] + s2 * q;
+            }
+            f32x4 a1[5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                u32x2 ph, pm, pl;
+                split4x3(ox[ps][s], ph, pm, pl);
+                f32x4 acc = mfma16(Fl, as_s4(ph), splat(0.f));       // smallest terms first
+                acc = mfma16(Fh, as_s4(pl), acc);
+                acc = mfma16(Fm, as_s4(pm), acc);
+                acc = mfma16(Fm, as_s4(ph), acc);
+                acc = mfma16(Fh, as_s4(pm), acc);
+                a1[s] = mfma16(Fh, as_s4(ph), acc);
+            }
+            a1[0] += b1;
+            f32x4 s0, s1, s2;
+            act012v<ACT>(a1[0], s0, s1, s2);
+            const f32x4 q = a1[1] * a1[1] + a1[2] * a1[2] + a1[3] * a1[3];
+            const f32x4 ol = s1 * a1[4] + s2 * q;
+            sv[ps][0] = s0;
+#pragma unroll
+            for (int s = 1; s < 5; s++) sv[ps][s] = a1[s];
+            const float Sv = xg_sum(dot4(wo, s0)), Sl = xg_sum(dot4(wo, ol));
+            SvT += (useB ? A.P : 1.0f) * Sv;
+            SlT += (useB ? A.P : 1.0f) * Sl;
+        }
+        Tail<float> t;
+        tail<float>(A.out_scale * SvT + bout, A.out_scale * SlT, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1,
+                    m2, A.invN, invN1, invN2, valid ? 1.0f : 0.0f, t);
+        if (MODE == MODE_FWD) {
+            if (valid && g == 0) {
+                if (A.psi) A.psi[idx] = t.psi;
+                if (A.lap) A.lap[idx] = t.lap;
+                if (A.res) A.res[idx] = t.res;
+            }
+            continue;
+        }
+        if (valid && g == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+        acc_pde += lead * t.l_pde;
+        acc_bc1 += lead * t.l_bc1;
+        acc_bc2 += lead * t.l_bc2;
+        acc_bout += lead * t.Nb;
+        if (MODE != MODE_BWD) continue;
+        // =========================== reverse ===========================
+#pragma unroll
+        for (int ps = NPASS - 1; ps >= 0; ps--) {
+            const bool useB = ps == 1;
+            float in[2][5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                in[0][s] = useB ? inA[1][s] : inA[0][s];
+                in[1][s] = useB ? inA[0][s] : inA[1][s];
+            }
+            const float pw = useB ? A.P : 1.0f;
+            const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
+            f32x4 yo[5];
+            {
+                const f32x4 h = sv[ps][0], a1x = sv[ps][1], a1y = sv[ps][2], a1z = sv[ps][3], a1l = sv[ps][4];
+                f32x4 s1, s2, s3;
+                act123v<ACT>(h, s1, s2, s3);
+                const f32x4 q = a1x * a1x + a1y * a1y + a1z * a1z;
+                woacc += cv * h + cl * (s1 * a1l + s2 * q);
+                const f32x4 o0 = cv * wo, olb = cl * wo;
+                const f32x4 u = 2.0f * s2 * olb;
+                yo[4] = s1 * olb;
+                yo[1] = u * a1x;
+                yo[2] = u * a1y;
+                yo[3] = u * a1z;
+                yo[0] = s1 * o0 + (s2 * a1l + s3 * q) * olb;
+                bacc1 += yo[0];
+            }
+            // ---- W1-bar += Y-bar (x) X over the 80 (stream, point) columns
+            u32x2 yh[5], yl[5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                u32x2 xh, xl;
+                split4(yo[s], yh[s], yl[s]);
+                split4(ox[ps][s], xh, xl);
+                const int off = (s * 16 + c) * PITCH + 4 * g;
+                *reinterpret_cast<u32x2*>(Yh + off) = yh[s];
+                *reinterpret_cast<u32x2*>(Yl + off) = yl[s];
+                *reinterpret_cast<u32x2*>(Xh + off) = xh;
+                *reinterpret_cast<u32x2*>(Xl + off) = xl;
+            }
+            wave_fence();
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                auto frag = [&](const __bf16* img) {
+                    const __bf16* p = img + (s * 16 + 4 * g + (c >> 2)) * PITCH + 4 * (c & 3);
+                    return __builtin_bit_cast(s16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                                         (__attribute__((address_space(3))) bf16x4*)p));
+                };
+                const s16x4 fyh = frag(Yh), fyl = frag(Yl), fxh = frag(Xh), fxl = frag(Xl);
+                wacc = mfma16(fyh, fxh, wacc);
+                wacc = mfma16(fyh, fxl, wacc);
+                wacc = mfma16(fyl, fxh, wacc);
+            }
+            wave_fence();
+            // ---- adjoint of the layer-0 outputs through W1^T, then layer 0 itself
+            f32x4 ob[5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                f32x4 acc = mfma16(Th, as_s4(yh[s]), splat(0.f));
+                acc = mfma16(Th, as_s4(yl[s]), acc);
+                ob[s] = mfma16(Tl, as_s4(yh[s]), acc);
+            }
+            {
+                f32x4 a0[5];
+#pragma unroll
+                for (int s = 1; s < 5; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
+                const f32x4 h = ox[ps][0];
+                f32x4 s1, s2, s3;
+                act123v<ACT>(h, s1, s2, s3);
+                const f32x4 q = a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3];
+                const f32x4 u = 2.0f * s2 * ob[4];
+                f32x4 ab[5];
+                ab[4] = s1 * ob[4];
+                ab[1] = s1 * ob[1] + u * a0[1];
+                ab[2] = s1 * ob[2] + u * a0[2];
+                ab[3] = s1 * ob[3] + u * a0[3];
+                ab[0] = s1 * ob[0] + s2 * (a0[1] * ob[1] + a0[2] * ob[2] + a0[3] * ob[3]) +
+                        (s2 * a0[4] + s3 * q) * ob[4];
+                bacc0 += ab[0];
+#pragma unroll
+                for (int s = 0; s < 5; s++) { w0acc0 += ab[s] * in[0][s]; w0acc1 += ab[s] * in[1][s]; }
+            }
+        }
+    }
+
+    if (MODE == MODE_FWD) return;
+    // =========================== block reduction ===========================
+    const float s0 = row16_sum(xg_sum(acc_pde)), s1r = row16_sum(xg_sum(acc_bc1)),
+                s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
+    if (MODE == MODE_BWD) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            bacc0[r] = row16_sum(bacc0[r]); bacc1[r] = row16_sum(bacc1[r]);
+            w0acc0[r] = row16_sum(w0acc0[r]); w0acc1[r] = row16_sum(w0acc1[r]);
+            woacc[r] = row16_sum(woacc[r]);
+        }
+    }
+    float* sc = gimg + PT;
+    __syncthreads();
+    for (int w = 0; w < kWavesPerBlock; w++) {
+        if (wave == w) {
+            const bool add = w != 0;
+            auto put = [&](float* p, float v) { *p = add ? *p + v : v; };
+            if (MODE == MODE_BWD) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) put(gimg + Lay::W(1) + (4 * g + r) * 16 + c, wacc[r]);
+                if (c == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int nj = 4 * g + r;
+                        put(gimg + Lay::b(0) + nj, bacc0[r]);
+                        put(gimg + Lay::b(1) + nj, bacc1[r]);
+                        put(gimg + Lay::W(0) + 2 * nj, w0acc0[r]);
+                        put(gimg + Lay::W(0) + 2 * nj + 1, w0acc1[r]);
+                        put(gimg + Lay::Wout + nj, woacc[r]);
+                    }
+                }
+            }
+            if (lane == 0) { put(sc + 0, s0); put(sc + 1, s1r); put(sc + 2, s2r); put(sc + 3, s3r); }
+        }
+        __syncthreads();
+    }
+    float* out = A.partial + (size_t)blockIdx.x * A.stride;
+    if (MODE == MODE_BWD) {
+        for (int k = threadIdx.x; k < PT; k += kBlock) out[k] = k == Lay::bout ? sc[3] : gimg[k];
+    } else {
+        for (int k = threadIdx.x; k < PT; k += kBlock) out[k] = 0.0f;
+    }
+    if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
+}
+
+template <int ACT, int NPASS>
+hipError_t launch_trunk16_t(int mode, const float* theta, const TrunkArgs& A, int grid, hipStream_t st)
+{
+    if (mode == MODE_FWD)
+        hipLaunchKernelGGL((k_trunk16<ACT, NPASS, MODE_FWD>), dim3(grid), dim3(kBlock), 0, st, theta, A);
+    else if (mode == MODE_BWD)
+        hipLaunchKernelGGL((k_trunk16<ACT, NPASS, MODE_BWD>), dim3(grid), dim3(kBlock), 0, st, theta, A);
+    else
+        hipLaunchKernelGGL((k_trunk16<ACT, NPASS, MODE_HEAD>), dim3(grid), dim3(kBlock), 0, st, theta, A);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // ---- R-only nets on the matrix pipe (see k_rnet_mfma_fwd / k_rnet_mfma_bwd)
@@ -1778,6 +2084,27 @@ hipError_t launch_rnet_mfma_bwd(int act, const float* thE, const float* R, const
     else
         hipLaunchKernelGGL(k_rnet_mfma_bwd<ACT_TANH>, dim3(grid), dim3(kBlock), 0, st, thE, R, Eb, gb, n, part, stride);
     return hipGetLastError();
+}
+
+// ---- the 16-wide reference trunk on the matrix pipe (see k_trunk16)
+bool trunk16_mfma_supported(int H, int L)
+{
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("PINN_TRUNK16_MFMA");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on && H == 16 && L == 2;
+}
+
+hipError_t launch_trunk16_mfma(int act, int npass, int mode, const float* theta, const TrunkArgs& A, int grid,
+                               hipStream_t st)
+{
+    if (act == ACT_SIGMOID)
+        return npass == 2 ? launch_trunk16_t<ACT_SIGMOID, 2>(mode, theta, A, grid, st)
+                          : launch_trunk16_t<ACT_SIGMOID, 1>(mode, theta, A, grid, st);
+    return npass == 2 ? launch_trunk16_t<ACT_TANH, 2>(mode, theta, A, grid, st)
+                      : launch_trunk16_t<ACT_TANH, 1>(mode, theta, A, grid, st);
 }
 
 bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }

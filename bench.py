@@ -40,8 +40,9 @@ def total_flops_per_point(H, L, HE, HG, n_pass):
 ARCHS = {
     "ref16": dict(H=16, L=2, HE=32, HG=10, act=0, n_pass=2, out_scale=1.0, precision="f32",
                   act_name="sigmoid", peak=157.3, dtype="f32",
-                  label="reference arch 2x16 trunk + 2x32 E-net + 1x10 gate, sigmoid, fp32 trunk "
-                        "(VALU + f32 MFMA; E-net 32x32 layer: split-bf16 MFMA), ionHsym weights"),
+                  label="reference arch 2x16 trunk + 2x32 E-net + 1x10 gate, sigmoid, fp32-grade: fp32 "
+                        "elementwise algebra, 16x16 / 32x32 layers as split-bf16 MFMA (3 pieces forward, 2 "
+                        "reverse, fp32 accumulate), ionHsym weights"),
     "wide64": dict(H=64, L=2, HE=32, HG=10, act=1, n_pass=2, out_scale=1.0, precision="bf16",
                    act_name="tanh", peak=2500.0, dtype="bf16",
                    label="2x64 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "
@@ -265,9 +266,10 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": TRAFFIC.get(args.arch),
                          "traffic_source": "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r01zz",
-                         "kernel": "k_trunk" if arch["dtype"] == "f32" else "k_trunk_mfma2",
+                         "kernel": ("k_trunk16" if arch["H"] == 16 else "k_trunk") if arch["dtype"] == "f32" else "k_trunk_mfma2",
                          "kernel_ms": trunk_ms, "flops_per_point": fl_trunk,
-                         "note": ("fp32 path: vector and f32-matrix peaks are both 157.3 TFLOP/s"
+                         "note": ("fp32-grade path: algorithmic flops against the fp32 vector peak (157.3 TFLOP/s); the layer GEMMs "
+                                  "run as split-bf16 MFMAs, the kernel is bound by its fp32 elementwise algebra"
                                   if arch["dtype"] == "f32" else
                                   "bf16 dense MFMA peak; algorithmic trunk flops only")},
             "loss": {"Ltot": Ltot, "Lpde": Lpde, "Lbc": Lbc},

@@ -37,9 +37,10 @@ typedef enum pinn_status {
 
 enum { PINN_ACT_SIGMOID = 0, PINN_ACT_TANH = 1 };
 enum {
-    PINN_PREC_F32 = 0,    /* fp32 trunk (VALU + exact f32 MFMA): the parity path.  On every setting the
-                             32x32 layer of the E-net runs on the bf16 pipe with split operands (three
-                             pieces = 24 bits in the forward; PINN_RNET_MFMA=0 selects exact fp32) */
+    PINN_PREC_F32 = 0,    /* fp32-grade, the parity path: fp32 elementwise algebra; the 16x16 trunk layer
+                             and (on every setting) the 32x32 E-net layer run on the bf16 pipe with split
+                             operands, three pieces = 24 bits in the forward sweep, fp32 accumulation.
+                             PINN_TRUNK16_MFMA=0 / PINN_RNET_MFMA=0 select the exact-fp32 kernels */
     PINN_PREC_BF16 = 1,   /* bf16 MFMA operands, fp32 accumulate and elementwise */
     PINN_PREC_BF16X3 = 2  /* split-bf16 (hi/lo, 3 products), fp32 accumulate */
 };

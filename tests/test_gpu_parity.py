@@ -717,6 +717,23 @@ def test_two_ranks_equal_one_rank_with_twice_the_points(tmp_path, golden_dir):
     assert tuple(r0["counts"]) == tuple(tr.counts.cpu().numpy())
 
 
+def test_exact_fp32_kernels_behind_the_switches():
+    """PINN_TRUNK16_MFMA=0 PINN_RNET_MFMA=0 select the exact-fp32 kernels (lane = point trunk with
+    packed-VALU mat-vecs, f32-MFMA R-nets) instead of the split-bf16 matrix-pipe ones: the same
+    reference-vector parity tests pass on them (the switches are read once per process, hence the
+    child process)"""
+    import subprocess
+    if os.environ.get("PINN_TRUNK16_MFMA") == "0":
+        pytest.skip("already inside the child run")
+    env = dict(os.environ, PINN_TRUNK16_MFMA="0", PINN_RNET_MFMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "forward_matches_reference or loss_and_gradient_match_reference or formulation_B "
+                        "or frozen_trunk_and_gate or adam_matches"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    assert " passed" in r.stdout
+
+
 def test_c_abi_from_plain_cpp_driver():
     """examples/train_capi.cpp: the library driven through include/pinn.h from C++/HIP alone (its
     own hipMalloc buffers and stream, no Python, no torch): samples, trains 120 steps at 50 000

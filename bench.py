@@ -80,7 +80,7 @@ ARCHS["wide4x64x3"] = dict(ARCHS["wide4x64"], precision="bf16x3", dtype="bf16x3"
                                  "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
 # HBM bytes per launch of each workload's trunk kernel from rocprofv3 PMC passes (FETCH_SIZE x 2 --
 # the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r01zz_final_default_bench.md)
-TRAFFIC = {"wide64": 71.7e6, "wide64x3": 40.1e6, "ref16": 33.2e6, "wide128": 81.4e6}
+TRAFFIC = {"wide64": 71.7e6, "wide64x3": 40.1e6, "ref16": 79.2e6, "wide128": 81.4e6}
 DEFAULT_ARCH = "wide64"
 SECONDARY = {"wide64": ["wide64x3", "ref16", "ref16ft", "wide128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
              "wide128": ["wide128x3"], "wide128x3": ["wide128"]}

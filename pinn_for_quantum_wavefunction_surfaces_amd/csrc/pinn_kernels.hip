@@ -1180,10 +1180,13 @@ static hipError_t prep_theta(pinn_handle* h, const float* theta, hipStream_t st)
 }
 
 // persistent grid of the trunk kernel for n points (also the number of partial rows k_reduce sums)
-static int trunk_grid(const pinn_handle* h, int64_t n)
+static int trunk_grid(const pinn_handle* h, int64_t n, int mode)
 {
     const pinn_arch& a = h->arch;
-    if (a.precision == PINN_PREC_F32 && trunk16_mfma_supported(a.H, a.L)) return grid16(n, h->nbT);
+    if (a.precision == PINN_PREC_F32 && trunk16_mfma_supported(a.H, a.L))
+        // k_trunk16: the reverse kernel holds two blocks per CU (256 registers), the forward-only
+        // sweeps (96-116 registers) four
+        return grid16(n, mode == MODE_BWD ? h->nbT / 2 : h->nbT);
     return grid_for(n, h->nbT);
 }
 
@@ -1236,7 +1239,7 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     // one resident 4-wave block per CU for both trunk kernels (1 wave per SIMD)
     const int bpc = arch->precision != PINN_PREC_F32
                         ? mfma_blocks_per_cu(arch->H, arch->L, arch->precision == PINN_PREC_BF16X3)
-                        : (trunk16_mfma_supported(arch->H, arch->L) ? 2 : 1);
+                        : (trunk16_mfma_supported(arch->H, arch->L) ? 4 : 1);
     h->nbT = (int)(tiles < (int64_t)cus * bpc ? tiles : (int64_t)cus * bpc);
     h->nbR = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
     h->strideT = h->PT + 3;
@@ -1379,7 +1382,7 @@ extern "C" int pinn_forward(pinn_handle* h, const float* theta, const float* x, 
     A.n = n; A.a = ham->a; A.b = ham->b; A.c = ham->c; A.P = ham->P; A.out_scale = a.out_scale;
     A.invN = 0.f; A.invN1 = 0.f; A.invN2 = 0.f;
     A.psi = psi; A.lap = lap; A.res = res;
-    if (!run_trunk(h, MODE_FWD, theta, A, trunk_grid(h, n), st, &e))
+    if (!run_trunk(h, MODE_FWD, theta, A, trunk_grid(h, n, MODE_FWD), st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L, precision)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_trunk<FWD>", e);
     return PINN_OK;
@@ -1398,7 +1401,9 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     hipError_t e = hipSuccess;
     const pinn_arch& a = h->arch;
     const bool rmfma = rnet_mfma_supported(a.HE, a.HG);
-    const int gT = trunk_grid(h, n), gR = rmfma ? grid16(n, h->nbR) : grid_for(n, h->nbR);
+    const bool trunk_trainable = (trainable_mask & h->trunk_tensors) != 0;
+    const int gT = trunk_grid(h, n, trunk_trainable ? MODE_BWD : MODE_HEAD);
+    const int gR = rmfma ? grid16(n, h->nbR) : grid_for(n, h->nbR);
     e = prep_theta(h, theta, st);
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_prep_theta", e);
     if (!rnet_forward(h, theta, R, n, nullptr, st, &e))
@@ -1410,7 +1415,6 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     A.invN = ham->invN; A.invN1 = ham->invN1; A.invN2 = ham->invN2;
     A.bc_counts = (const long long*)bc_counts;
     A.Eb = h->Eb; A.gb = h->gb; A.partial = h->partT; A.stride = h->strideT;
-    const bool trunk_trainable = (trainable_mask & h->trunk_tensors) != 0;
     const int slot = h->prof_slots ? (int)(h->prof_calls % h->prof_slots) : 0;
     if (h->prof_slots) HIPCHK(h, hipEventRecord(h->ev[2 * slot], st));
     if (!run_trunk(h, trunk_trainable ? MODE_BWD : MODE_HEAD, theta, A, gT, st, &e))

@@ -1769,7 +1769,7 @@ __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c)
 }
 
 template <int ACT, int NPASS, int MODE>
-__global__ __launch_bounds__(kBlock, 2) void k_trunk16(const float* __restrict__ theta, TrunkArgs A)
+__global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(const float* __restrict__ theta, TrunkArgs A)
 {
     using Lay = TrunkLayout<16, 2>;
     constexpr int PT = Lay::size;

@@ -1174,6 +1174,9 @@ static int rnet_forward(pinn_handle* h, const float* theta, const float* R, int6
 static hipError_t prep_theta(pinn_handle* h, const float* theta, hipStream_t st)
 {
     const pinn_arch& a = h->arch;
+    // the input-major copy only feeds the lane = point kernels (k_trunk, k_rnet_fwd/bwd)
+    const bool trunk_needs = a.precision == PINN_PREC_F32 && !trunk16_mfma_supported(a.H, a.L);
+    if (!trunk_needs && rnet_mfma_supported(a.HE, a.HG)) return hipSuccess;
     hipLaunchKernelGGL(k_prep_theta, dim3((h->P + 255) / 256), dim3(256), 0, st, theta, h->thT, a.H, a.L,
                        a.HE, h->PT, h->P);
     return hipGetLastError();

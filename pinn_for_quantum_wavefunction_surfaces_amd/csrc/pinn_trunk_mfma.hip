@@ -1841,9 +1841,11 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
         const float F = inA[0][0] + A.P * inA[1][0];
         const float lapF = inA[0][4] + A.P * inA[1][4];
 
-        // saved forward state per pass: layer-0 output streams (the X operand of the weight
-        // gradient; stream 0 is the layer-0 activation) and (h, a_x, a_y, a_z, a_lap) of layer 1
-        f32x4 ox[NPASS][5], sv[NPASS][5];
+        // saved forward state per pass: the layer-0 output streams as their two leading bf16 pieces
+        // (exactly the X operand of the weight gradient), the layer-0 activation in fp32, and
+        // (h, a_x, a_y, a_z, a_lap) of layer 1
+        u32x2 xh[NPASS][5], xl[NPASS][5];
+        f32x4 h0s[NPASS], sv[NPASS][5];
         float SvT = 0.f, SlT = 0.f;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ps++) {
@@ -1854,7 +1856,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
                 in[0][s] = useB ? inA[1][s] : inA[0][s];
                 in[1][s] = useB ? inA[0][s] : inA[1][s];
             }
-            f32x4 a0[5];
+            f32x4 a0[5], ox[5];
 #pragma unroll
             for (int s = 0; s < 5; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
             a0[0] += b0;
@@ -1862,17 +1864,20 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
                 f32x4 s0, s1, s2;
                 act012v<ACT>(a0[0], s0, s1, s2);
                 const f32x4 q = a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3];
-                ox[ps][0] = s0;
-                ox[ps][1] = s1 * a0[1];
-                ox[ps][2] = s1 * a0[2];
-                ox[ps][3] = s1 * a0[3];
-                ox[ps][4] = s1 * a0[4] + s2 * q;
+                ox[0] = s0;
+                ox[1] = s1 * a0[1];
+                ox[2] = s1 * a0[2];
+                ox[3] = s1 * a0[3];
+                ox[4] = s1 * a0[4] + s2 * q;
+                h0s[ps] = s0;
             }
             f32x4 a1[5];
 #pragma unroll
             for (int s = 0; s < 5; s++) {
                 u32x2 ph, pm, pl;
-                split4x3(ox[ps][s], ph, pm, pl);
+                split4x3(ox[s], ph, pm, pl);
+                xh[ps][s] = ph;
+                xl[ps][s] = pm;
                 f32x4 acc = mfma16(Fl, as_s4(ph), splat(0.f));       // smallest terms first
                 acc = mfma16(Fh, as_s4(pl), acc);
                 acc = mfma16(Fm, as_s4(pm), acc);
@@ -1941,14 +1946,12 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             u32x2 yh[5], yl[5];
 #pragma unroll
             for (int s = 0; s < 5; s++) {
-                u32x2 xh, xl;
                 split4(yo[s], yh[s], yl[s]);
-                split4(ox[ps][s], xh, xl);
                 const int off = (s * 16 + c) * PITCH + 4 * g;
                 *reinterpret_cast<u32x2*>(Yh + off) = yh[s];
                 *reinterpret_cast<u32x2*>(Yl + off) = yl[s];
-                *reinterpret_cast<u32x2*>(Xh + off) = xh;
-                *reinterpret_cast<u32x2*>(Xl + off) = xl;
+                *reinterpret_cast<u32x2*>(Xh + off) = xh[ps][s];
+                *reinterpret_cast<u32x2*>(Xl + off) = xl[ps][s];
             }
             wave_fence();
 #pragma unroll
@@ -1976,7 +1979,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
                 f32x4 a0[5];
 #pragma unroll
                 for (int s = 1; s < 5; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
-                const f32x4 h = ox[ps][0];
+                const f32x4 h = h0s[ps];
                 f32x4 s1, s2, s3;
                 act123v<ACT>(h, s1, s2, s3);
                 const f32x4 q = a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3];

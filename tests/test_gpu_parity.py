@@ -734,6 +734,32 @@ def test_exact_fp32_kernels_behind_the_switches():
     assert " passed" in r.stdout
 
 
+def test_error_paths_report_and_leave_the_handle_usable():
+    """negative status codes, never a crash: batch above the capacity given at create, null
+    buffers, Ry/Rz != 0, unsupported shapes; the handle keeps working afterwards"""
+    arch, f = make()
+    h = capi.Handle(arch, 0, 1000)
+    theta = torch.zeros(h.P, device=DEV)
+    pts = [torch.rand(2000, device=DEV) for _ in range(4)]
+    out = torch.empty(h.P + 3, device=DEV)
+    with pytest.raises(capi.PinnError, match="max_points"):
+        h.residual_fwd_bwd(theta, *pts, None, 2000, ham_of(f, 2000, 1, 1), None, (1 << 63) - 1, out)
+    with pytest.raises(capi.PinnError):
+        h.forward(theta, pts[0], None, pts[2], pts[3], 500, ham_of(f, 500, 1, 1), psi=out[:500])
+    bad = ham_of(f, 500, 1, 1)
+    bad.Ry = 0.5
+    with pytest.raises(capi.PinnError, match="Ry/Rz"):
+        h.forward(theta, *[p[:500] for p in pts], 500, bad, psi=out[:500])
+    with pytest.raises(capi.PinnError, match="unsupported"):
+        capi.Handle(capi.Arch(48, 2, 32, 10, 0, 2, 1.0, 0), 0, 1000)        # no 48-wide trunk
+    with pytest.raises(capi.PinnError, match="unsupported"):
+        capi.Handle(capi.Arch(16, 2, 32, 10, 0, 2, 1.0, capi.PINN_PREC_BF16), 0, 1000)   # bf16 needs H >= 64
+    psi = torch.empty(500, device=DEV)
+    h.forward(theta, *[p[:500] for p in pts], 500, ham_of(f, 500, 1, 1), psi=psi)  # still fine
+    torch.cuda.synchronize()
+    assert torch.isfinite(psi).all()
+
+
 def test_c_abi_from_plain_cpp_driver():
     """examples/train_capi.cpp: the library driven through include/pinn.h from C++/HIP alone (its
     own hipMalloc buffers and stream, no Python, no torch): samples, trains 120 steps at 50 000

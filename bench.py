@@ -289,7 +289,7 @@ def main():
                 "parity": PARITY[oarch["precision"]], "loss": {"Ltot": olosses[0]}})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(theta0, arch)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -7,7 +7,6 @@ freezeDecayUnit, plus the free functions set_params, exactE, radial, V, sampling
 Nothing here computes psi with torch ops: forward and LossFunctions call the
 C ABI (include/pinn.h) and raise if the HIP library or a GPU is missing.
 """
-import ctypes as C
 
 import numpy as np
 import torch

@@ -10,6 +10,9 @@
  * stream (passed as void*, NULL = default stream); nothing here synchronises.
  * Every function returns 0 on success or a negative pinn_status; nothing
  * throws or exits.  A handle is not thread-safe; distinct handles are independent.
+ * One handle = one stream at a time: the handle's scratch (per-point E, g and their adjoints,
+ * per-block gradient partials, packed weights) is shared by every call on it, so two calls on the
+ * same handle must be ordered on ONE stream (or by events); use one handle per concurrent stream.
  *
  * Parameter vector `theta` (P floats): tensors in NN_ion registration order
  * (poc/main.py:234-245) -- Lin_H1 .. Lin_H{L}, Lin_out, Lin_E1, Lin_E2, Lin_Eout,

@@ -54,7 +54,8 @@ def _to_model(params, device):
 def train(params, lr, epochs, n=None, Rlo=None, Rhi=None, L=None, cutoff=None, bcutoff=None,
           device="cuda", seed=12345, verbose=False):
     """train.py:21-73.  `params`: the 16 tensors (updated IN PLACE with the best parameters, like
-    train.py:65-69).  Returns {"Ltot", "Lpde", "Lbc", "Lbest"} with one row per step."""
+    train.py:65-69).  Returns {"Ltot", "Lpde", "Lbc", "Lbest"} with one row per optimizer step;
+    "Lfinal" is the loss of the closing evaluation (train.py's pass tt == epochs)."""
     d = DEFAULTS
     n = d["n"] if n is None else n
     box = d["L"] if L is None else L
@@ -74,7 +75,8 @@ def train(params, lr, epochs, n=None, Rlo=None, Rhi=None, L=None, cutoff=None, b
         if verbose and tt % 10 == 0:                     # train.py:61-64 (this one synchronises)
             l = hist[tt].tolist()
             print("%8d: %.2e %.2e %.2e [%.5e]" % (tt, sum(l), l[0], l[1] + l[2], float(best[tt])))
-    torch.cuda.synchronize()
+    tr.evaluate(resample=True, track_best=True)          # train.py:24-69: pass epochs + 1 only evaluates,
+    torch.cuda.synchronize()                             # so the final parameters can become the best
     tr.sync_to_model(best=True)                          # train.py:65-69
     arrs = formats.state_dict_to_bin_arrays(model.state_dict())
     with torch.no_grad():
@@ -82,7 +84,7 @@ def train(params, lr, epochs, n=None, Rlo=None, Rhi=None, L=None, cutoff=None, b
             t.copy_(torch.tensor(a, dtype=t.dtype).reshape(t.shape))
     h = hist.cpu().numpy().astype(np.float64)
     return {"Ltot": h.sum(1), "Lpde": h[:, 0].copy(), "Lbc": h[:, 1:].sum(1),
-            "Lbest": best.cpu().numpy().astype(np.float64)}
+            "Lbest": best.cpu().numpy().astype(np.float64), "Lfinal": float(tr.grad[tr.P:].sum())}
 
 
 def write_model_bin(path, params):

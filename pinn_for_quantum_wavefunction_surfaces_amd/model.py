@@ -319,6 +319,8 @@ def sampling(params, n_points, linearSampling=False, device="cuda", seed=12345, 
     else:
         if dev.type != "cuda":
             raise capi.PinnError("sampling() draws on the GPU (pinn_sample); no CPU fallback")
+        from .trainer import check_cubic_box
+        check_cubic_box(params)
         m = model if model is not None else NN_ion(params)
         h = m._handle_for(dev, n_points)
         x, y, z, R = [torch.empty(n_points, device=dev, dtype=torch.float32) for _ in range(4)]

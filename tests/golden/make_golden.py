@@ -13,6 +13,7 @@ numbers (inputs + outputs) as .npz files.
 What is produced:
   g1_weights.npz   both checkpoints as flat fp64 vectors (state_dict order)
   g2_formA_*.npz   NN_ion (poc/main.py) on a fixed batch: psi,E,lap,Hpsi,res,losses,grads
+                   (tanh64 / tanh16: the same module with its `sig` handle set to nn.Tanh())
   g3_formB.npz     train.py formulation on a fixed batch (its own statements, its `d`)
   g4_adam_*.npz    10 torch.optim.Adam steps on stored batches (full and frozen trunk)
   g5_energy.npz    poc/energy_R_ion.pkl table (parsed opcode-by-opcode, never unpickled)
@@ -181,6 +182,17 @@ def gen_form_A(ns):
     torch.manual_seed(13)
     out["rand32"] = eval_form_A(ns, NN_ion(params, 32, 16, 8), xs[:512], ys[:512], zs[:512],
                                 Rs[:512])
+    # tanh: the reference's only activation handle is NN_ion.sig (poc/main.py:231), used by the
+    # trunk, the E-net and the gate alike; swapping that module is all it takes to run the
+    # reference's unchanged forward / LossFunctions / autograd with tanh (BASELINE "2x64 tanh")
+    torch.manual_seed(17)
+    m64 = NN_ion(params, 64, 32, 10)
+    m64.sig = torch.nn.Tanh()
+    out["tanh64"] = eval_form_A(ns, m64, xs, ys, zs, Rs)
+    torch.manual_seed(19)
+    m16 = NN_ion(params)
+    m16.sig = torch.nn.Tanh()
+    out["tanh16"] = eval_form_A(ns, m16, xs, ys, zs, Rs)
     for tag, dct in out.items():
         np.savez_compressed(os.path.join(OUT, "g2_formA_%s.npz" % tag), **dct)
         print("g2_formA_%s: Ltot=%.6e |grad|=%.3e" % (tag, dct["Ltot"],

@@ -93,6 +93,24 @@ def test_loss_and_gradient_match_reference(golden_dir, tag):
         assert np.max(np.abs(out[o:o + s] - ref)) < 2e-4 * max(np.max(np.abs(ref)), 1e-3 * np.max(np.abs(g["grad"])))
 
 
+def test_tanh_reference_arch_matches_reference(golden_dir):
+    """tanh pinned to the reference: poc/main.py's NN_ion with its `sig` handle set to nn.Tanh()
+    (make_golden.py), 16/32/10 widths, on the fp32 parity path (k_trunk16 + matrix-pipe R-nets)"""
+    g = np.load(os.path.join(golden_dir, "g2_formA_tanh16.npz"))
+    arch, f = make(dict(act=1))
+    h = capi.Handle(arch, 0, 4096)
+    psi, E, lap, res = run_forward(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"])
+    assert rel(psi, g["psi"]) < 1e-5 and rel(E, g["E"]) < 1e-5
+    assert rel(lap, g["lap"]) < 1e-5 and rel(res, g["res"]) < 2e-5
+    out = run_loss_grad(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"], g["mask"])
+    P = h.P
+    assert abs(out[P:].sum() / g["Ltot"] - 1) < 1e-4 and rel(out[:P], g["grad"]) < 1e-4
+    off, sz = capi.tensor_layout(arch)
+    for o, s_ in zip(off, sz):
+        ref = g["grad"][o:o + s_]
+        assert np.max(np.abs(out[o:o + s_] - ref)) < 2e-4 * max(np.max(np.abs(ref)), 1e-3 * np.max(np.abs(g["grad"])))
+
+
 def test_formulation_B_matches_train_py(golden_dir):
     g = np.load(os.path.join(golden_dir, "g3_formB.npz"))
     arch, f = make(form="B")
@@ -231,7 +249,6 @@ def test_sampler_is_bit_exact_and_counts_feed_the_kernel():
         assert np.array_equal(got.cpu().numpy(), want)
     assert np.array_equal(mask.cpu().numpy(), omask)
     assert tuple(counts.tolist()) == ocnt
-    # clamp branch (probability ~1e-11 per point, so force it): seed the oracle's rule
     # device-side counts give the same result as host-side 1/N1, 1/N2
     w = np.load(os.path.join(os.path.dirname(__file__), "golden", "g1_weights.npz"))["ionHsym"]
     th = dev32(w)
@@ -240,6 +257,65 @@ def test_sampler_is_bit_exact_and_counts_feed_the_kernel():
     h.residual_fwd_bwd(th, x, y, z, R, mask, n, ham_of(f, n, ocnt[0], ocnt[1]), None, (1 << 63) - 1, o2)
     torch.cuda.synchronize()
     assert torch.equal(o1, o2)
+
+
+def test_sampler_nucleus_clamp_branch_is_bit_exact():
+    """train.py:32-35 / poc/main.py:147-149: points closer than `cutoff` to a nucleus get x := cutoff
+    (an assignment, not a projection).  With the reference's cutoff (0.005) the branch has probability
+    ~1e-11 per point, so it is forced here: cutoff 6, BC cutoff 4 -> tens of thousands of points take it,
+    and the BC masks of those points depend on whether the radii are taken before or after the clamp
+    (train.py:36-39 recomputes them after)."""
+    arch, f = make()
+    n, first, cutoff, bc = 300007, 12345, 6.0, 4.0
+    h = capi.Handle(arch, 0, n)
+    x, y, z, R = [torch.empty(n, device=DEV) for _ in range(4)]
+    mask = torch.empty(n, device=DEV, dtype=torch.uint8)
+    counts = torch.zeros(2, device=DEV, dtype=torch.int64)
+    h.sample(777, 3, first, n, 18.0, 0.2, 4.0, cutoff, bc, x, y, z, R, mask, counts)
+    torch.cuda.synchronize()
+    ox, oy, oz, oR, omask, ocnt = O.sample(777, 3, first, n, cutoff=cutoff, bc_cutoff=bc)
+    xs, ys, zs, Rs = [t.cpu().numpy() for t in (x, y, z, R)]
+    for got, want in ((xs, ox), (ys, oy), (zs, oz), (Rs, oR)):
+        assert np.array_equal(got, want)
+    assert np.array_equal(mask.cpu().numpy(), omask) and tuple(counts.tolist()) == ocnt
+    # independent statement of the rule in numpy (fp64 on the fp32 outputs)
+    X, Y, Z, RR = [a.astype(np.float64) for a in (xs, ys, zs, Rs)]
+    clamped = xs == np.float32(cutoff)
+    assert 5000 < clamped.sum() < 0.2 * n              # the branch really ran, thousands of times
+    r1 = np.sqrt((X - RR) ** 2 + Y ** 2 + Z ** 2)
+    r2 = np.sqrt((X + RR) ** 2 + Y ** 2 + Z ** 2)
+    # every point that kept its x was outside both spheres (its radii ARE the pre-clamp radii)
+    assert np.minimum(r1, r2)[~clamped].min() >= cutoff * (1 - 1e-6)
+    # masks use the post-clamp radii: recompute from the returned (clamped) coordinates
+    m = (r1 >= bc).astype(np.uint8) + 2 * (r2 >= bc).astype(np.uint8)
+    edge = (np.abs(r1 - bc) < 1e-4) | (np.abs(r2 - bc) < 1e-4)     # fp32 vs fp64 at the threshold
+    assert np.array_equal(m[~edge], omask[~edge])
+    # ... and that is observable: many clamped points sit outside the BC radius of one nucleus only
+    # because x moved to `cutoff` (before the clamp they were within `cutoff` of that nucleus or the other)
+    assert (m[clamped] != 0).sum() > 1000
+
+
+def test_empty_boundary_sets_contribute_zero(golden_dir):
+    """Lbc over an empty index set is NaN in the reference (mean of an empty tensor; SURVEY appendix
+    C.4, unreachable at n >= 100); here an empty set contributes exactly 0 -- documented deviation --
+    both with host-side 1/N_bc = 0 and with device-side counts of 0"""
+    g = np.load(os.path.join(golden_dir, "g2_formA_ionHsym.npz"))
+    arch, f = make()
+    inner = np.where(g["mask"] == 0)[0][:500]
+    x, y, z, R = [g[k][inner] for k in ("x", "y", "z", "R")]
+    n = len(inner)
+    mask = np.zeros(n, np.uint8)
+    h = capi.Handle(arch, 0, 4096)
+    out = run_loss_grad(h, f, g["theta"], x, y, z, R, mask)
+    assert np.all(np.isfinite(out)) and out[h.P + 1] == 0 and out[h.P + 2] == 0
+    ref = O.loss_grad(O.arch(), O.ham_A(), g["theta"], x, y, z, R, mask, invN1=0.0, invN2=0.0)
+    assert abs(out[h.P] / ref["Lpde"] - 1) < 1e-4 and rel(out[:h.P], ref["grad"]) < 1e-4
+    o2 = torch.empty(h.P + 3, device=DEV)
+    h.residual_fwd_bwd(dev32(g["theta"]), dev32(x), dev32(y), dev32(z), dev32(R),
+                       torch.tensor(mask, device=DEV), n, ham_of(f, n),
+                       torch.zeros(2, device=DEV, dtype=torch.int64), (1 << 63) - 1, o2)
+    torch.cuda.synchronize()
+    assert np.array_equal(o2.cpu().numpy().astype(np.float64), out)
 
 
 def test_adam_matches_torch_optim_semantics(golden_dir):
@@ -380,6 +456,106 @@ def test_mfma_bf16_wide_trunk_matches_reference(golden_dir):
                O.arch(H=64), O.ham_A())
 
 
+def _tensor_errors(arch, L, got, ref):
+    off, sz = capi.tensor_layout(arch)
+    names = [k for l in range(L) for k in ("W%d" % l, "b%d" % l)] + ["wout", "bout", "WE1", "bE1", "WE2", "bE2",
+                                                                      "WE3", "bE3", "WG1", "bG1", "WG2", "bG2"]
+    return {nm: np.max(np.abs(got[off[t]:off[t] + sz[t]] - ref[off[t]:off[t] + sz[t]]))
+            / max(np.max(np.abs(ref[off[t]:off[t] + sz[t]])), 1e-3 * np.max(np.abs(ref)))
+            for t, nm in enumerate(names)}
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_benchmarked_2x64_tanh_instance_matches_reference(golden_dir, prec):
+    """THE instance bench.py times -- k_trunk_mfma2<64, 2, TANH, NPASS = 2, MODE_BWD> in bf16 (primary
+    workload) and split-bf16 (the wide64x3 record) -- against numbers produced by the reference's own
+    NN_ion(params, 64, 32, 10) with sig = nn.Tanh(), its LossFunctions and autograd (g2_formA_tanh64):
+    psi, lap, residual, loss, the whole gradient and every tensor's gradient on its own"""
+    g = np.load(os.path.join(golden_dir, "g2_formA_tanh64.npz"))
+    f = pkg.model.FORMULATION_A
+    pr = capi.PINN_PREC_BF16 if prec == "bf16" else capi.PINN_PREC_BF16X3
+    arch = capi.Arch(64, 2, 32, 10, 1, f["n_pass"], f["out_scale"], pr)
+    h = capi.Handle(arch, 0, 4096)
+    theta, x, y, z, R, mask = [g[k] for k in ("theta", "x", "y", "z", "R", "mask")]
+    psi, E, lap, res = run_forward(h, f, theta, x, y, z, R)
+    out = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    P = h.P
+    errs = dict(psi=rel(psi, g["psi"]), E=rel(E, g["E"]), lap=rel(lap, g["lap"]), res=rel(res, g["res"]),
+                loss=abs(out[P:].sum() / g["Ltot"] - 1), grad=rel(out[:P], g["grad"]))
+    terr = _tensor_errors(arch, 2, out[:P], g["grad"])
+    print("2x64 tanh %s vs reference:" % prec, {k: "%.2e" % v for k, v in {**errs, **terr}.items()})
+    assert errs["E"] < 1e-5
+    if prec == "bf16":       # this path's own tolerance (header of this section)
+        assert errs["psi"] < 1e-2 and errs["lap"] < 1e-2 and errs["res"] < 2e-2
+        assert errs["loss"] < 3e-2 and errs["grad"] < 3e-2
+        assert max(terr.values()) < 6e-2, terr
+    else:                    # fp32-grade: north_star's 1e-5 on psi; same bars as the split-bf16 section
+        assert errs["psi"] < 1e-5 and errs["lap"] < 1e-5 and errs["res"] < 5e-5
+        assert errs["loss"] < 2e-4 and errs["grad"] < 2e-4
+        assert max(terr.values()) < 4e-4, terr
+    assert np.array_equal(out, run_loss_grad(h, f, theta, x, y, z, R, mask))
+
+
+def test_benchmarked_instance_at_full_size_shards_add_up_and_match_oracle():
+    """BASELINE config 2 at its real size: 1 000 000 points through the bf16 2x64 tanh kernel on its
+    full persistent grid (every other MFMA test stays at <= 4096 points = a few blocks).
+    Size-independent properties: per-point outputs of the big launch equal those of 16 separate
+    launches over its 62 500-point shards bit for bit; the big launch's [grad | losses] equals the
+    sum of the shard launches to fp32 round-off; and a 4 096-point sample of the per-point outputs,
+    plus the first shard's gradient, agree with the fp64 oracle at the bf16 tolerance."""
+    n, nsh = 1000000, 16
+    f = pkg.model.FORMULATION_A
+    arch = capi.Arch(64, 2, 32, 10, 1, f["n_pass"], f["out_scale"], capi.PINN_PREC_BF16)
+    A = O.arch(H=64, act=1)
+    rng = np.random.default_rng(2026)
+    off, sz = O.tensor_layout(A)
+    theta = np.zeros(O.param_count(A))
+    fan = [2, 2, 64, 64, 64, 64, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    for o, s_, fi in zip(off, sz, fan):
+        theta[o:o + s_] = rng.uniform(-1, 1, s_) / np.sqrt(fi)
+    h = capi.Handle(arch, 0, n)
+    x, y, z, R = [torch.empty(n, device=DEV) for _ in range(4)]
+    mask = torch.empty(n, device=DEV, dtype=torch.uint8)
+    counts = torch.zeros(2, device=DEV, dtype=torch.int64)
+    h.sample(99, 0, 0, n, 18.0, 0.2, 4.0, 0.005, 17.5, x, y, z, R, mask, counts)
+    th = dev32(theta)
+    n1, n2 = [int(c) for c in counts.tolist()]
+    ham = ham_of(f, n, n1, n2)
+    big = torch.empty(h.P + 3, device=DEV)
+    h.residual_fwd_bwd(th, x, y, z, R, mask, n, ham, None, (1 << 63) - 1, big)
+    outs = [torch.empty(n, device=DEV) for _ in range(4)]
+    h.forward(th, x, y, z, R, n, ham_of(f), *outs)
+    tot = torch.zeros(h.P + 3, device=DEV, dtype=torch.float64)
+    part = torch.empty(h.P + 3, device=DEV)
+    m = n // nsh
+    first = None
+    for k in range(nsh):
+        sl = slice(k * m, (k + 1) * m)
+        h.residual_fwd_bwd(th, x[sl], y[sl], z[sl], R[sl], mask[sl], m, ham, None, (1 << 63) - 1, part)
+        tot += part.double()
+        if k == 0:
+            first = part.clone()
+        o2 = [torch.empty(m, device=DEV) for _ in range(4)]
+        h.forward(th, x[sl], y[sl], z[sl], R[sl], m, ham_of(f), *o2)
+        for a, b in zip(outs, o2):
+            assert torch.equal(a[sl], b), k
+    torch.cuda.synchronize()
+    big64, tot = big.double().cpu().numpy(), tot.cpu().numpy()
+    P = h.P
+    assert rel(big64[:P], tot[:P]) < 2e-5 and abs(big64[P:].sum() / tot[P:].sum() - 1) < 2e-5
+    # oracle on a sample of the per-point outputs and on the first shard's gradient
+    idx = rng.choice(n, 4096, replace=False)
+    xs, ys, zs, Rs = [t[idx].cpu().numpy().astype(np.float64) for t in (x, y, z, R)]
+    fw = O.forward(A, O.ham_A(), theta, xs, ys, zs, Rs)
+    psi, E, lap, res = [o[idx].cpu().numpy().astype(np.float64) for o in outs]
+    assert rel(psi, fw["psi"]) < 1e-2 and rel(E, fw["E"]) < 1e-5 and rel(lap, fw["lap"]) < 1e-2
+    assert rel(res, fw["res"]) < 2e-2
+    sl = slice(0, m)
+    ref = O.loss_grad(A, O.ham_A(), theta, *[t[sl].cpu().numpy().astype(np.float64) for t in (x, y, z, R)],
+                      mask[sl].cpu().numpy(), invN=1.0 / n, invN1=1.0 / n1, invN2=1.0 / n2)
+    assert rel(first[:P].double().cpu().numpy(), ref["grad"]) < 3e-2
+
+
 @pytest.mark.parametrize("H,L,form,act", [(64, 2, "B", 1), (128, 2, "A", 0), (128, 2, "B", 1),
                                            (64, 4, "A", 1), (128, 4, "A", 1), (128, 4, "B", 0)])
 def test_mfma_bf16_matches_oracle(H, L, form, act):
@@ -485,7 +661,8 @@ def test_fine_tune_recipe_moves_E_of_R_toward_the_exact_curve(golden_dir):
     model = pkg.NN_ion(params).to(DEV)
     model.load_flat_params(torch.tensor(W["ionHsym"]))
     before = mean_err(model)
-    model, hist = pkg.train(params, loadWeights=False, freezeUnits=True, model=model, verbose=False)
+    model, hist = pkg.train(params, loadWeights=False, freezeUnits=True, model=model, verbose=False,
+                            save=False)
     after = mean_err(model)
     ref = pkg.NN_ion(params).to(DEV)
     ref.load_flat_params(torch.tensor(W["fineTune"]))
@@ -498,15 +675,45 @@ def test_fine_tune_recipe_moves_E_of_R_toward_the_exact_curve(golden_dir):
 def test_reference_style_train_driver_runs(tmp_path):
     """train(params, ...) mirror of poc/main.py:359-430: history schema and decreasing loss"""
     params = pkg.set_params()
-    params.update(epochs=60, n_train=20000, lossPath=str(tmp_path / "loss.pkl"))
+    params.update(epochs=60, n_train=20000, lossPath=str(tmp_path / "loss.pkl"),
+                  saveModelPath=str(tmp_path / "best.pt"), sc_sampling=2)
     torch.manual_seed(0)
     model, hist = pkg.train(params, verbose=False)
     assert set(hist) == {"Ltot", "Lbc", "Lpde", "Energy"}
     assert all(v.shape == (60, 1) and v.dtype == np.float64 for v in hist.values())
     assert np.allclose(hist["Ltot"], hist["Lpde"] + hist["Lbc"], rtol=1e-5)
     assert hist["Ltot"][-1, 0] < 0.5 * hist["Ltot"][0, 0]
-    pkg.saveLoss(params, hist)
-    assert os.path.getsize(params["lossPath"]) > 0
+    # side effects of poc/main.py:414-427: loss pickle (saveLoss) and the best checkpoint in
+    # saveModel's schema, best = lowest loss after 50 % of the epochs, weights AFTER that step
+    import pickle
+    with open(params["lossPath"], "rb") as fh:          # a file this test's own run wrote
+        assert set(pickle.load(fh)) == set(hist)
+    ck = torch.load(params["saveModelPath"], map_location="cpu", weights_only=True)
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict"}
+    assert list(ck["model_state_dict"]) == list(model.state_dict())
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), ck["model_state_dict"][k].cpu()), k
+    st = ck["optimizer_state_dict"]["state"]
+    assert sorted(st) == list(range(16))
+    kbest = 31 + int(np.argmin(hist["Ltot"][31:, 0]))   # steps with tt > 0.5 * epochs
+    assert float(st[0]["step"]) == kbest + 1 and st[0]["step"].dtype == torch.float64
+    assert st[2]["exp_avg"].shape == (16, 16) and st[2]["exp_avg_sq"].min() >= 0
+    g = ck["optimizer_state_dict"]["param_groups"][0]
+    assert g["lr"] == params["lr"] and tuple(g["betas"]) == (0.9, 0.999) and g["params"] == list(range(16))
+    m2 = pkg.NN_ion(params)
+    m2.loadModel(dict(params, loadModelPath=params["saveModelPath"]))   # poc/main.py:325-329
+    assert torch.equal(m2.Lin_H2.weight, model.Lin_H2.weight.cpu().to(m2.Lin_H2.weight.dtype))
+    # Llim (poc/main.py:372): a run whose loss never drops below 10 restores / saves nothing
+    p2 = dict(params, epochs=4, saveModelPath=str(tmp_path / "none.pt"), lossPath="")
+    pkg.train(p2, verbose=False, model=_blown_up_model(p2))
+    assert not os.path.exists(p2["saveModelPath"])
+
+
+def _blown_up_model(params):
+    m = pkg.NN_ion(params)
+    with torch.no_grad():
+        m.Lin_out.weight.mul_(300.0)                    # |psi| ~ 1e2 everywhere: Ltot >> 10
+    return m
 
 
 def test_flat_train_py_surface(tmp_path):
@@ -664,21 +871,25 @@ def test_one_message_pipelined_step_equals_plain_step(golden_dir):
 
         a, b = make(False), make(True)
         assert b.pipelined and not a.pipelined
-        b.resample()                                   # batch 0 (the steps then sample one ahead)
         for i in range(6):
             a.step()
-            xa, ca = a.x.clone(), a.counts.clone()     # the batch step i used
-            xb, cb = b.x.clone(), b.counts.clone()     # b: read BEFORE its step (buffers swap)
-            b.step()
-            assert torch.equal(xa, xb) and torch.equal(ca, cb), i
+            b.step()                                   # after a step: x, counts = the batch it trained on
+            assert torch.equal(a.x, b.x) and torch.equal(a.counts, b.counts), i
             assert torch.equal(a.grad, b.grad), i
         torch.cuda.synchronize()
         assert torch.equal(a.theta, b.theta)
         assert int(b.step_count.item()) == 6
-        b.step(resample=False)                         # frozen point set (end of train()): no swap
-        xb = b.x.clone()
-        b.step(resample=False)
-        assert torch.equal(xb, b.x) and int(b.step_count.item()) == 8
+        # sc_sampling = 2 and the frozen tail of poc/main.py:396: non-resampling steps keep the batch
+        # of the step before, the next resampling step t trains on Philox step t -- on both paths
+        for i, (rs, nxt) in enumerate([(True, 2), (False, 1), (True, 2), (False, 0), (False, 0), (True, 1)]):
+            xa_prev = a.x.clone()
+            a.step(resample=rs, next_resample=nxt)
+            b.step(resample=rs, next_resample=nxt)
+            assert torch.equal(a.x, b.x) and torch.equal(a.counts, b.counts), i
+            assert torch.equal(a.x, xa_prev) != rs, i
+            assert torch.equal(a.grad, b.grad), i
+        torch.cuda.synchronize()
+        assert torch.equal(a.theta, b.theta) and int(b.step_count.item()) == 12
     finally:
         if own:
             dist.destroy_process_group()

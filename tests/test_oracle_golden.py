@@ -15,7 +15,10 @@ from oracle import oracle as O
 
 TOL = 1e-12
 ARCHS = dict(ionHsym=(16, 32, 10), fineTune=(16, 32, 10), rand16=(16, 32, 10),
-             rand64=(64, 32, 10), rand32=(32, 16, 8))
+             rand64=(64, 32, 10), rand32=(32, 16, 8), tanh64=(64, 32, 10), tanh16=(16, 32, 10))
+# tanh64 / tanh16: the reference's NN_ion with its activation handle `sig` (poc/main.py:231) set to
+# nn.Tanh() -- BASELINE's "2x64 tanh" workload pinned to the reference's own forward and autograd
+ACT = dict(tanh64=1, tanh16=1)
 
 
 def rel(a, b):
@@ -26,7 +29,7 @@ def rel(a, b):
 def test_formulation_A_matches_reference_autograd(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, "g2_formA_%s.npz" % tag))
     H, HE, HG = ARCHS[tag]
-    A, Hm = O.arch(H=H, HE=HE, HG=HG), O.ham_A()
+    A, Hm = O.arch(H=H, HE=HE, HG=HG, act=ACT.get(tag, 0)), O.ham_A()
     assert O.param_count(A) == g["theta"].size
     f = O.forward(A, Hm, g["theta"], g["x"], g["y"], g["z"], g["R"])
     assert rel(f["psi"], g["psi"]) < TOL
@@ -157,7 +160,8 @@ def test_sampler_contract_statistics():
 
 
 def test_extension_tanh_multilayer_gradcheck():
-    """L>2 and tanh are not in the reference; check the oracle's adjoint by finite differences."""
+    """L>2 is not in the reference (tanh at L = 2 is pinned by g2_formA_tanh*.npz); check the oracle's
+    adjoint for the deeper trunk by finite differences."""
     A = O.arch(H=8, L=3, HE=6, HG=4, act=1, n_pass=2)
     Hm = O.ham_A()
     rng = np.random.default_rng(0)
@@ -203,7 +207,7 @@ def test_committed_fixtures_regenerate_bit_identically(tmp_path, golden_dir):
     subprocess.run([sys.executable, os.path.join(golden_dir, "make_golden.py")], check=True, env=env,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     files = sorted(glob.glob(os.path.join(golden_dir, "*.npz")))
-    assert len(files) >= 12
+    assert len(files) >= 14
     for f in files:
         a, b = np.load(f), np.load(os.path.join(str(tmp_path), os.path.basename(f)))
         assert sorted(a.files) == sorted(b.files), f

@@ -76,3 +76,120 @@ def test_two_shards_equal_one(tmp_path):
     got1 = np.load(tmp_path / "dp1.npy")
     assert np.abs(got1[:P] - ref["grad"]).max() / np.abs(ref["grad"]).max() < 1e-6
     assert tuple(np.load(tmp_path / "counts_next.npy")) == O.sample(12345, 4, 0, world * n_local)[5]
+
+
+# ----------------------------------------------------------------------------------------------
+# The Trainer's step sequencing (pinn_..._amd/trainer.py) over gloo, world size 2: which batch a step
+# trains on, when the point buffers swap, the one-message exchange and its two-collective fallback
+# (taken automatically at >= 2^24 global points).  The kernels are stood in for by the CPU oracle
+# through the Trainer's `handle` test seam; everything else is the product's code.
+class OracleHandle:
+    """capi.Handle's call surface on CPU tensors, backed by the oracle (test infrastructure)"""
+    P = 1521                                           # reference architecture (overwritten per instance)
+
+    def __init__(self, O, A, Hm):
+        self.O, self.A, self.Hm = O, A, Hm
+        self.P = O.param_count(A)
+        self.calls = []
+
+    def sample(self, seed, step, first, n, box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask, counts,
+               step_dev=None):
+        st = int(step) + (int(step_dev.item()) if step_dev is not None else 0)
+        self.calls.append(("sample", st))
+        ox, oy, oz, oR, om, oc = self.O.sample(seed, st, first, n, box, Rlo, Rhi, cutoff, bc_cutoff)
+        for dst, src in ((x, ox), (y, oy), (z, oz), (R, oR), (mask, om)):
+            dst.copy_(torch.from_numpy(src))
+        if counts is not None:
+            counts.copy_(torch.tensor(oc, dtype=torch.int64))
+
+    def residual_fwd_bwd(self, theta, x, y, z, R, mask, n, ham, bc_counts, tmask, out):
+        c = [int(v) for v in bc_counts.tolist()]
+        f64 = lambda t: t.numpy().astype(np.float64)
+        lg = self.O.loss_grad(self.A, self.Hm, f64(theta), f64(x), f64(y), f64(z), f64(R), mask.numpy(),
+                              invN=float(ham.invN), invN1=1.0 / c[0] if c[0] else 0.0,
+                              invN2=1.0 / c[1] if c[1] else 0.0, trainable_mask=tmask)
+        s = lg["sums"]
+        out.copy_(torch.tensor(np.concatenate([lg["grad"], [s[0] * ham.invN, s[1] / max(c[0], 1),
+                                                            s[2] / max(c[1], 1)]]), dtype=torch.float32))
+
+    def adam(self, theta, grad, m, v, step_count, lr, b1, b2, eps, tmask, best_theta=None, best_loss=None):
+        th, g, mm, vv = [t.numpy().astype(np.float64) for t in (theta, grad[:self.P], m, v)]
+        step_count += 1
+        self.O.adam(self.A, th, np.ascontiguousarray(g), mm, vv, int(step_count.item()), lr, b1, b2, eps,
+                    trainable_mask=tmask)
+        for dst, src in ((theta, th), (m, mm), (v, vv)):
+            dst.copy_(torch.tensor(src, dtype=torch.float32))
+
+
+# (resample, next_resample) per step: every step; sc_sampling = 2 with hints; a frozen tail; a wrong hint
+SCHEDULE = [(True, 1), (True, 2), (False, 1), (True, 2), (False, 0), (False, 0), (True, 3), (True, 1), (False, 1),
+            (True, 0), (True, 1)]
+
+
+def _run_trainer(plan, pipelined, n_local):
+    from oracle import oracle as O
+    import pinn_for_quantum_wavefunction_surfaces_amd as pkg
+    params = pkg.set_params()
+    model = pkg.NN_ion(params)
+    model.load_flat_params(torch.tensor(np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))["ionHsym"]))
+    h = OracleHandle(O, O.arch(), O.ham_A())
+    tr = pkg.Trainer(model, params, n_points=n_local, lr=8e-3, device="cpu", plan=plan, pipelined=pipelined,
+                     handle=h)
+    xs, cs, ls = [], [], []
+    for rs, nxt in SCHEDULE:
+        tr.step(resample=rs, next_resample=nxt)
+        xs.append(tr.x.clone().numpy())
+        cs.append(tr.counts.clone().numpy())
+        ls.append(tr.losses()[0])
+    return tr, h, np.array(xs), np.array(cs), np.array(ls)
+
+
+def _trainer_worker(rank, world, port, n_local, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pinn_for_quantum_wavefunction_surfaces_amd.parallel import DataParallelPlan
+    torch.set_num_threads(2)
+    for tag, pipe in (("pipe", None), ("plain", False)):
+        tr, h, xs, cs, ls = _run_trainer(DataParallelPlan(n_local), pipe, n_local)
+        assert tr.pipelined == (pipe is None)
+        np.savez(os.path.join(out_dir, "%s_rank%d.npz" % (tag, rank)), theta=tr.theta.numpy(), xs=xs, cs=cs, ls=ls,
+                 nsample=sum(1 for c in h.calls if c[0] == "sample"))
+
+    class Huge(DataParallelPlan):                      # 2 x 8M points and more: counts no longer exact in fp32
+        n_global = property(lambda self: 1 << 24)
+    import pinn_for_quantum_wavefunction_surfaces_amd as pkg
+    p = pkg.set_params()
+    t = pkg.Trainer(pkg.NN_ion(p), p, n_points=64, device="cpu", plan=Huge(64), handle=OracleHandle.__new__(OracleHandle))
+    assert t.plan.collectives and not t.pipelined      # the fallback is taken by itself
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_sequencing_two_ranks_equal_one(tmp_path):
+    sys.path.insert(0, ROOT)
+    from pinn_for_quantum_wavefunction_surfaces_amd.parallel import DataParallelPlan
+    world, n_local = 2, 400
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_trainer_worker, args=(world, port, n_local, str(tmp_path)), nprocs=world, join=True)
+    tr, h, xs, cs, ls = _run_trainer(DataParallelPlan(world * n_local, rank=0, world=1), None, world * n_local)
+    assert not tr.pipelined
+    # one rank: a resampling step t draws Philox step t, the others keep the batch
+    drawn = [c[1] for c in h.calls if c[0] == "sample"]
+    assert drawn == [t for t, (rs, _) in enumerate(SCHEDULE) if rs]
+    for tag in ("pipe", "plain"):
+        r = [np.load(tmp_path / ("%s_rank%d.npz" % (tag, k))) for k in range(world)]
+        assert np.array_equal(r[0]["theta"], r[1]["theta"])                  # ranks stay bit-identical
+        for k in range(world):
+            # every step trained on this rank's shard of the single-rank batch of that step
+            assert np.array_equal(r[k]["xs"], xs[:, k * n_local:(k + 1) * n_local]), tag
+            assert np.array_equal(r[k]["cs"], cs), tag                       # global set sizes
+            assert np.abs(r[k]["ls"] / ls - 1).max() < 1e-5, tag
+        assert np.abs(r[0]["theta"] - tr.theta.numpy()).max() < 5e-5 * np.abs(tr.theta.numpy()).max(), tag
+    # the plain path samples once per resampling step; the pipelined one once per hint (+ the first batch
+    # and the two steps whose hint was missing or wrong)
+    assert int(np.load(tmp_path / "plain_rank0.npz")["nsample"]) == sum(rs for rs, _ in SCHEDULE)

@@ -629,11 +629,18 @@ struct M2Cfg {
     // (4x128: 192 KB) they are streamed through two one-matrix LDS buffers (WSTREAM), or, in
     // split-bf16 mode, the A fragments are read from global memory, where they stay L2-resident
     static constexpr bool WLDS = (size_t)WPK_ALL * 2 <= 64 * 1024;
-    // WSTREAM (bf16 only): one layer matrix at a time, double-buffered in LDS by LDS-DMA
-    // (global_load_lds_dwordx4) while the previous layer computes; the packed set stays in L2
-    static constexpr bool WSTREAM = !WLDS && !X3;
     // split-bf16 whose two planes do not fit: the hi plane sits in LDS, the lo plane is read from L2
     static constexpr bool WHI = X3 && !WLDS && (size_t)(WPK_ALL / 2) * 2 <= 64 * 1024;
+    // WSTREAM: one layer matrix (its hi plane in split-bf16 mode) at a time, double-buffered in LDS by
+    // LDS-DMA (global_load_lds_dwordx4) while the previous layer computes; the packed set stays in L2,
+    // where the lo plane of split-bf16 is read from
+    static constexpr bool WSTREAM = !WLDS && !WHI;
+    // XONE (4x128 split-bf16: three two-plane layer-output buffers do not fit): ONE exchange buffer for
+    // layer outputs.  The forward overwrites it layer by layer (one more barrier per layer); the reverse
+    // sweep rebuilds the outputs of layer l-2 from the saved state just before the weight gradient of
+    // layer l-1 needs them as its X operand.
+    static constexpr bool XONE = X3 && !WLDS && !WHI && L > 2;
+    static constexpr int NXL = XONE ? 1 : L - 1;                  // resident layer-output buffers per pass slot
     static constexpr int WPK = WLDS ? WPK_ALL : (WSTREAM ? 2 * H * H : (WHI ? WPK_ALL / 2 : 0));
     // deep wide trunks keep the k loop rolled: unrolled, the scheduler hoists all 20 B-fragment
     // reads of a layer and the kernel spills
@@ -656,10 +663,11 @@ struct M2Cfg {
     // KEEP: every pass of the symmetric double pass has its own XB buffers (and register slot),
     // so the reverse sweeps reuse the forward state instead of recomputing pass A -- when the
     // second set fits the 160 KB of LDS (for all OCC resident blocks of a CU)
-    static constexpr bool KEEP = OCC >= 1 && OCC * (OFF_GRP + (size_t)GROUPS * (2 * (L - 1) * EB + EB + SBYTES)) <= 160 * 1024;
+    static constexpr bool KEEP = !XONE && OCC >= 1 && OCC * (OFF_GRP + (size_t)GROUPS * (2 * (L - 1) * EB + EB + SBYTES)) <= 160 * 1024;
     static constexpr int NXB = KEEP ? 2 : 1;
-    static constexpr int GBYTES = NXB * (L - 1) * EB + EB + SBYTES;   // XB[slot][0..L-2], YB, S
+    static constexpr int GBYTES = NXB * NXL * EB + EB + SBYTES;   // XB[slot][0..NXL-1], YB, S
     static constexpr size_t LDS_BYTES = OFF_GRP + (size_t)GROUPS * GBYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "exchange buffers + weights exceed the CU's LDS");
 };
 
 template <int H, int L, int ACT, int NPASS, int MODE, int SPLIT, int WAVES, bool X3, int OCC>
@@ -693,9 +701,11 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
     constexpr bool KEEP = C::KEEP && NPASS == 2;
     constexpr bool SVF = C::SVF32;
     constexpr int NS = KEEP ? 2 : 1;                    // pass slots (registers and XB sets)
-    const lds_p XB = gbase;                             // [slot][(L-1)] exchange buffers: outputs of layers 0..L-2
-    const lds_p YB = gbase + C::NXB * (L - 1) * C::EB;  // adjoint exchange buffer
-    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_GRP + (size_t)grp * C::GBYTES + (size_t)C::NXB * (L - 1) * C::EB + C::EB);   // [SPLIT][16][2]
+    constexpr bool XONE = C::XONE;
+    constexpr int NXL = C::NXL;
+    const lds_p XB = gbase;                             // [slot][NXL] exchange buffers: outputs of layers 0..L-2
+    const lds_p YB = gbase + C::NXB * NXL * C::EB;      // adjoint exchange buffer
+    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_GRP + (size_t)grp * C::GBYTES + (size_t)C::NXB * NXL * C::EB + C::EB);   // [SPLIT][16][2]
     const int lane16 = lane * 16;                       // lane-linear 16-byte fragment slot
     // transposed-read lane offset: row (8g + 4hh + (c>>2)) -> stream half (g>>1), point 8(g&1)+(c>>2);
     // 8-byte piece (c&1) of chunk ((c&3)>>1) of the tile: everything else is an immediate
@@ -748,8 +758,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
             reinterpret_cast<unsigned*>(lds_raw + C::OFF_ZERO)[k] = 0u;
     }
     const __bf16* wsrc = (C::WLDS || C::WHI) ? wpk : wpk_g;   // one provenance per instantiation
-    // lo plane: behind the hi plane in the same image, or (WHI) in global memory
-    const __bf16* wlo_f = C::WHI ? wpk_g + WPLANE : wsrc + WPLANE;
+    // lo plane: behind the hi plane in the same image, or (WHI, WSTREAM) in global memory
+    const __bf16* wlo_f = (C::WHI || C::WSTREAM) ? wpk_g + WPLANE : wsrc + WPLANE;
     // ---- weight streaming: matrix use k reads LDS buffer k & 1; at the start of use k every wave
     // copies its share of use k+1's matrix into the other buffer (free since the barrier that ended
     // use k-1); the barrier that ends use k drains the copy (vmcnt(0)) before anyone reads it.
@@ -828,7 +838,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
         f32x4 h0[NS][RT];
         auto fwd = [&](const bool useB, auto SLc, float& Sv, float& Sl, const int wnext) {
             constexpr int SL = decltype(SLc)::value;
-            const lds_p XBs = XB + SL * (L - 1) * C::EB;
+            const lds_p XBs = XB + SL * NXL * C::EB;
             float in[2][5];
 #pragma unroll
             for (int s = 0; s < 5; s++) {
@@ -870,7 +880,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
             for (int l = 1; l < L; l++) {
                 wstage(l < L - 1 ? l * 2 : wnext, wuse + 1);
                 const __bf16* wf = WSTREAM ? wcur() : wsrc + (size_t)((l - 1) * 2 + 0) * H * H;
-                const lds_p xin = XBs + (l - 1) * C::EB + lane16;
+                const __bf16* wfl = wlo_f + (size_t)((l - 1) * 2 + 0) * H * H;   // lo plane of the same matrix
+                const lds_p xin = XBs + (XONE ? 0 : l - 1) * C::EB + lane16;
                 f32x4 a[RT][5];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
@@ -905,9 +916,9 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     bf16x8 wa[RT], wl[RT];
 #pragma unroll
                     for (int tt = 0; tt < RT; tt++) {
-                        const __bf16* pw = wf + (((RT * part + tt) * KC + kc) * 64 + lane) * 8;
-                        wa[tt] = *reinterpret_cast<const bf16x8*>(pw);
-                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(wlo_f + (pw - wsrc)) : wa[tt];
+                        const int fo = (((RT * part + tt) * KC + kc) * 64 + lane) * 8;
+                        wa[tt] = *reinterpret_cast<const bf16x8*>(wf + fo);
+                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(wfl + fo) : wa[tt];
                     }
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
@@ -949,7 +960,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     }
                 }
                 if (l < L - 1) {
-                    const lds_p xout = XBs + l * C::EB;
+                    const lds_p xout = XBs + (XONE ? 0 : l) * C::EB;
+                    if (XONE) __syncthreads();   // one buffer: everyone is done reading layer l-1's outputs
 #pragma unroll
                     for (int s = 0; s < 5; s++) put_split(xout, s, o[s]);
                     __syncthreads();
@@ -967,7 +979,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
         };
         auto rev = [&](const bool useB, auto SLc, const int wnext) {
             constexpr int SL = decltype(SLc)::value;
-            const lds_p XBs = XB + SL * (L - 1) * C::EB;
+            const lds_p XBs = XB + SL * NXL * C::EB;
             float in[2][5];
 #pragma unroll
             for (int s = 0; s < 5; s++) {
@@ -1011,7 +1023,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
             __syncthreads();
 #pragma unroll
             for (int l = L - 1; l >= 1; l--) {
-                const lds_p xin = XBs + (l - 1) * C::EB;
+                const lds_p xin = XBs + (XONE ? 0 : l - 1) * C::EB;
                 wstage(l - 1 >= 1 ? (l - 2) * 2 + 1 : wnext, wuse + 1);
                 // ---- W_l-bar[own rows][all columns] += Y-bar (x) X, 32 of the 80 columns per phase,
                 //      both operands read transposed straight out of the exchange buffers
@@ -1057,6 +1069,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                 }
                 // ---- adjoint of layer l's input for the own neurons, then layer l-1's activation adjoint
                 const __bf16* wb = WSTREAM ? wcur() : wsrc + (size_t)((l - 1) * 2 + 1) * H * H;
+                const __bf16* wbl = wlo_f + (size_t)((l - 1) * 2 + 1) * H * H;
                 f32x4 ob[RT][5];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++)
@@ -1089,9 +1102,9 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     bf16x8 wa[RT], wl[RT];
 #pragma unroll
                     for (int tt = 0; tt < RT; tt++) {
-                        const __bf16* pwb = wb + (((RT * part + tt) * KC + kc) * 64 + lane) * 8;
-                        wa[tt] = *reinterpret_cast<const bf16x8*>(pwb);
-                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(wlo_f + (pwb - wsrc)) : wa[tt];
+                        const int fo = (((RT * part + tt) * KC + kc) * 64 + lane) * 8;
+                        wa[tt] = *reinterpret_cast<const bf16x8*>(wb + fo);
+                        wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(wbl + fo) : wa[tt];
                     }
 #pragma unroll
                     for (int s = 0; s < 5; s++) {
@@ -1148,9 +1161,41 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     }
                 }
                 if (l - 1 >= 1) {   // hand the next layer's adjoints to the group
-                    __syncthreads();   // everyone is done reading YB
+                    __syncthreads();   // everyone is done reading YB (and, XONE, the layer-output buffer)
 #pragma unroll
                     for (int s = 0; s < 5; s++) put_split(YB, s, yo[s]);
+                    if constexpr (XONE) {
+                        // the next weight gradient (layer l-1) contracts with the outputs of layer l-2:
+                        // rebuild them from that layer's saved state into the one layer-output buffer
+                        f32x4 xo[5][RT];
+#pragma unroll
+                        for (int tt = 0; tt < RT; tt++) {
+                            f32x4 h, a[5];
+                            if (l - 2 == 0) {
+                                const int n0 = 16 * (RT * part + tt) + 4 * g;
+                                const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2);
+                                const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2 + 4);
+                                const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
+#pragma unroll
+                                for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
+                                h = h0[SL][tt];
+                            } else {
+                                h = svf[SL][l - 3 >= 0 ? l - 3 : 0][tt][0];
+#pragma unroll
+                                for (int s = 1; s < 5; s++) a[s] = svf[SL][l - 3 >= 0 ? l - 3 : 0][tt][s];
+                            }
+                            f32x4 s1, s2, s3;
+                            act123v<ACT>(h, s1, s2, s3);
+                            const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                            xo[0][tt] = h;
+                            xo[1][tt] = s1 * a[1];
+                            xo[2][tt] = s1 * a[2];
+                            xo[3][tt] = s1 * a[3];
+                            xo[4][tt] = s1 * a[4] + s2 * q;
+                        }
+#pragma unroll
+                        for (int s = 0; s < 5; s++) put_split(XBs, s, xo[s]);
+                    }
                     __syncthreads();
                 }
                 if (WSTREAM) wuse++;
@@ -2111,7 +2156,7 @@ hipError_t launch_trunk16_mfma(int act, int npass, int mode, const float* theta,
 }
 
 bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
-bool mfma_x3_supported(int H, int L) { return ((H == 64 || H == 128) && L == 2) || (H == 64 && L == 4); }
+bool mfma_x3_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
 
 // A/B switch for measurements (see launch_trunk_mfma): PINN_MFMA_GEN = 0 (default: the fastest
 // measured decomposition), 1..3 = alternatives.
@@ -2161,6 +2206,9 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
             // hi weight plane in LDS (64 KB), lo plane from L2, one pass resident: 4.3 ms
             return launch2_HL<128, 2, 8, 8, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         }
+        if (H == 128 && L == 4)   // BASELINE config 1 (4x128 fp32-grade): hi plane streamed through LDS by
+                                  // LDS-DMA, lo plane from L2, one layer-output buffer (XONE)
+            return launch2_HL<128, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         return false;
     }
     if (H == 64 && L == 2) {

@@ -1019,8 +1019,10 @@ def test_c_abi_from_plain_cpp_driver():
 # PINN_PREC_BF16X3: every MFMA operand is hi + lo (two bf16), three MFMAs per product, fp32
 # accumulate, saved pre-activations kept in fp32.  16 operand mantissa bits instead of 8: this is
 # the wide path that meets the 1e-5 bar on psi (north_star) while still running on the bf16 pipe.
-@pytest.mark.parametrize("H,L,tag", [(64, 2, "rand64"), (128, 2, None), (64, 4, None)])
-def test_mfma_split_bf16_meets_the_fp32_bar(golden_dir, H, L, tag):
+@pytest.mark.parametrize("H,L,tag,act", [(64, 2, "rand64", 0), (128, 2, None, 0), (64, 4, None, 0),
+                                             (128, 4, None, 1), (128, 4, None, 0), (64, 4, None, 1)])
+def test_mfma_split_bf16_meets_the_fp32_bar(golden_dir, H, L, tag, act):
+    """(128, 4): BASELINE config 1's "4x128 MLP, fp32" -- the fp32-grade wide path at that shape"""
     if tag:
         g = np.load(os.path.join(golden_dir, "g2_formA_%s.npz" % tag))   # reference-generated
         theta, x, y, z, R, mask = [g[k] for k in ("theta", "x", "y", "z", "R", "mask")]
@@ -1037,9 +1039,9 @@ def test_mfma_split_bf16_meets_the_fp32_bar(golden_dir, H, L, tag):
         R = rng.uniform(0.2, 4, n)
         mask = ((np.sqrt((x - R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8)
                 + 2 * (np.sqrt((x + R) ** 2 + y ** 2 + z ** 2) >= 17.5).astype(np.uint8))
-    A, Hm = O.arch(H=H, L=L), O.ham_A()
+    A, Hm = O.arch(H=H, L=L, act=act), O.ham_A()
     f = pkg.model.FORMULATION_A
-    arch = capi.Arch(H, L, 32, 10, 0, 2, 1.0, capi.PINN_PREC_BF16X3)
+    arch = capi.Arch(H, L, 32, 10, act, 2, 1.0, capi.PINN_PREC_BF16X3)
     h = capi.Handle(arch, 0, 4096)
     fw = O.forward(A, Hm, theta, x, y, z, R)
     ref = O.loss_grad(A, Hm, theta, x, y, z, R, mask)
@@ -1047,7 +1049,9 @@ def test_mfma_split_bf16_meets_the_fp32_bar(golden_dir, H, L, tag):
     out = run_loss_grad(h, f, theta, x, y, z, R, mask)
     errs = dict(psi=rel(psi, fw["psi"]), lap=rel(lap, fw["lap"]), res=rel(res, fw["res"]),
                 loss=abs(out[h.P:].sum() / ref["Ltot"] - 1), grad=rel(out[:h.P], ref["grad"]))
-    print("mfma split-bf16 errors:", {k: "%.2e" % v for k, v in errs.items()})
+    terr = _tensor_errors(arch, L, out[:h.P], ref["grad"])
+    print("mfma split-bf16 errors (%dx%d act %d):" % (L, H, act), {k: "%.2e" % v for k, v in {**errs, **terr}.items()})
     assert errs["psi"] < 1e-5 and errs["lap"] < 1e-5 and errs["res"] < 5e-5
     assert errs["loss"] < 2e-4 and errs["grad"] < 2e-4
+    assert max(terr.values()) < 4e-4, terr
     assert np.array_equal(out, run_loss_grad(h, f, theta, x, y, z, R, mask))

@@ -151,11 +151,9 @@ def _median_step_time(step, batch, warm=2, reps=5, budget_s=8.0):
 def cpu_baseline(theta_np, arch, gpu_check=None):
     """The reference formulation (nested autograd.grad Laplacian, loss, backward, torch.optim.Adam;
     oracle/torch_baseline.py) in PyTorch on the host's CPU cores, on a BOUNDED sample:
-      * `value`: the reference's own architecture (2x16 sigmoid trunk, the only one it has) at its own
-        batch size, n = 100 000 (poc/main.py:39), fp64 (the reference's dtype), on all host threads torch
-        uses by default -- median of 5 steps after 2 warm-ups;
-      * `fp32`: the same in fp32; `threads16`: fp64 on 16 threads (the small per-op work of this
-        formulation does not scale to a whole socket -- reported, not used as `value`);
+      * the reference's own architecture (2x16 sigmoid trunk, the only one it has) at its own batch size,
+        n = 100 000 (poc/main.py:39), median of 5 steps after 2 warm-ups: fp64 (the reference's dtype) on all
+        host threads torch uses by default and on 16 threads (`value` = the faster), fp32 on 16 threads;
       * `primary_arch`: the benchmark's primary architecture (nested autograd through its wider layers),
         fp64, 20 000 points.
     The same leg also CHECKS the GPU path (gpu_check): a few thousand of the benchmark's own points and
@@ -173,28 +171,35 @@ def cpu_baseline(theta_np, arch, gpu_check=None):
     ncpu = os.cpu_count() or 1
     w = np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))["ionHsym"]
     legs, n = {}, 100000
-    for tag, dtype, nt in (("fp64", torch.float64, nthreads_all), ("fp32", torch.float32, nthreads_all),
-                           ("fp64_16thr", torch.float64, min(16, ncpu))):
+    for tag, dtype, nt in (("fp64", torch.float64, nthreads_all), ("fp64_16thr", torch.float64, min(16, ncpu)),
+                           ("fp32_16thr", torch.float32, min(16, ncpu))):
         torch.set_num_threads(nt)
         _, step = TB.make_step(torch.tensor(w), REF_ARCH, HAM_A, lr=8e-3, dtype=dtype)
-        dt, k = _median_step_time(step, make_batch(n, dtype))
+        dt, k = _median_step_time(step, make_batch(n, dtype), warm=1 if tag == "fp64" else 2,
+                                  reps=3 if tag == "fp64" else 5)
         legs[tag] = {"value": n / dt, "unit": "points/s", "s_per_step": dt, "steps": k, "threads": nt}
         print("[cpu_baseline] reference arch n=%d %s %d threads: %.3f s/step" % (n, tag, nt, dt),
               file=sys.stderr, flush=True)
-    torch.set_num_threads(nthreads_all)
-    out = {"value": legs["fp64"]["value"], "unit": "points/s", "cores": nthreads_all, "kind": "port",
+    torch.set_num_threads(legs["fp64_16thr"]["threads"])
+    # `value` = the FASTER of the two fp64 runs: the ~700 small ops per step of this formulation do not
+    # scale to a whole socket (all cores can be several times slower than 16 threads), and a baseline
+    # slowed by oversubscription would flatter the GPU number
+    best = max(("fp64", "fp64_16thr"), key=lambda k: legs[k]["value"])
+    out = {"value": legs[best]["value"], "unit": "points/s", "cores": legs[best]["threads"], "kind": "port",
            "sample": "reference architecture (2x16 sigmoid trunk + 2x32 E-net + 1x10 gate, ionHsym weights), "
                      "n = 100 000 points/step, fp64, median of %d steps after 2 warm-ups, PyTorch-CPU restatement "
-                     "of the reference formulation (nested autograd.grad Laplacian + backward + Adam) on %d "
-                     "threads (torch default) of %d host CPUs" % (legs["fp64"]["steps"], nthreads_all, ncpu),
-           "fp32": legs["fp32"], "threads16": legs["fp64_16thr"]}
+                     "of the reference formulation (nested autograd.grad Laplacian + backward + Adam); run on %d "
+                     "threads (torch's default = all physical cores of the %d host CPUs) and on 16 threads, the "
+                     "faster of the two (%d threads) is `value`"
+                     % (legs[best]["steps"], nthreads_all, ncpu, legs[best]["threads"]),
+           "fp64_all_cores": legs["fp64"], "fp64_16_threads": legs["fp64_16thr"], "fp32_16_threads": legs["fp32_16thr"]}
     if arch["H"] != 16:
         n2 = 20000
         a2 = {k: arch[k] for k in ("H", "L", "HE", "HG", "act", "n_pass", "out_scale")}
         _, step = TB.make_step(torch.tensor(theta_np), a2, HAM_A, lr=8e-3, dtype=torch.float64)
         dt, k = _median_step_time(step, make_batch(n2, torch.float64), warm=1, reps=3, budget_s=10.0)
         out["primary_arch"] = {"value": n2 / dt, "unit": "points/s", "s_per_step": dt, "steps": k,
-                               "threads": nthreads_all, "sample": "%dx%d %s trunk, %d points, fp64"
+                               "threads": torch.get_num_threads(), "sample": "%dx%d %s trunk, %d points, fp64"
                                % (arch["L"], arch["H"], arch["act_name"], n2)}
     if gpu_check is not None:
         out["parity_observed"] = gpu_check(TB)
@@ -280,12 +285,16 @@ def main():
             step = tr.step
             if not args.no_prewarm:
                 # untimed: keep the GPU busy for >= 0.3 s so that a short driver run (--steps 20) measures
-                # steady clocks instead of the ramp from idle; the timed region below is unchanged
+                # steady clocks instead of the ramp from idle; the timed region below is unchanged.  The
+                # step count is agreed over the ranks (every step is a collective when N > 1).
                 t_w = time.perf_counter()
-                while time.perf_counter() - t_w < 0.3:
-                    for _ in range(10):
-                        step()
-                    torch.cuda.synchronize()
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
+                per_step = plan.max_over_ranks((time.perf_counter() - t_w) / 10, dev)
+                for _ in range(min(int(0.3 / max(per_step, 1e-5)) + 1, 3000)):
+                    step()
+                torch.cuda.synchronize()
             tr.h.profile_enable(min(max(args.steps, 1), 1024))
             for _ in range(args.warmup):
                 step()
@@ -327,7 +336,7 @@ def main():
         rel = lambda got, ref: float((got.double().cpu().reshape(-1) - ref.detach().reshape(-1)).abs().max()
                                      / ref.detach().abs().max())
         return {"points": n, "psi": rel(outs[0], psi), "E": rel(outs[1], E), "lap": rel(outs[2], lap),
-                "res": rel(outs[3], res), "loss": abs(float(g[h.P:].sum()) / float(Ltot) - 1),
+                "res": rel(outs[3], res), "loss": abs(float(g[h.P:].sum()) / float(Ltot.detach()) - 1),
                 "grad": rel(g[:h.P], t64.grad), "against": "fp64 PyTorch-CPU restatement of the reference "
                 "formulation, same points, same weights (max-norm relative errors)"}
 

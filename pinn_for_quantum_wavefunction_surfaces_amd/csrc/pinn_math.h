@@ -145,6 +145,24 @@ PINN_HD void orbital(T dx, T dy, T dz, T st[5], T& rinv)
     st[4] = f + T(2) * fr;  // f (1 - 2/r)
 }
 
+// The same orbital in the cylindrical frame of its point: (value, d/dx, d/drho, Laplacian) with
+// rho = sqrt(y^2 + z^2).  Both orbitals' gradients lie in the plane spanned by x^ and rho^, so these four
+// streams carry what the five Cartesian ones do (|grad|^2 = d_x^2 + d_rho^2; the Laplacian stream keeps
+// the full 3-D Laplacian f (1 - 2/r)).  rho = 0 is regular: d/drho = -f rho / r = 0.
+template <class T>
+PINN_HD void orbital_cyl(T dx, T rho2, T rho, T st[4], T& rinv)
+{
+    T r2 = dx * dx + rho2;
+    rinv = p_rsqrt(r2);
+    T r = r2 * rinv;
+    T f = p_exp(-r);
+    T fr = -f * rinv;
+    st[0] = f;
+    st[1] = fr * dx;
+    st[2] = fr * rho;
+    st[3] = f + T(2) * fr;  // f (1 - 2/r)
+}
+
 // -------------------------------------------------------------------- trunk
 // pair versions of the activation helpers: the transcendental unit works per half, everything
 // else is packed arithmetic

@@ -56,6 +56,16 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+// Streams per neuron.  The reference differentiates in Cartesian coordinates (value, d/dx, d/dy, d/dz,
+// Laplacian: five streams).  Both orbitals' gradients -- hence every neuron's -- lie in the plane spanned
+// by x^ and rho^ = (0, y, z)/rho, so |grad a|^2 = a_x^2 + a_rho^2 and FOUR streams (value, d/dx, d/drho,
+// Laplacian) carry exactly the same information: 4/5 of the GEMM columns and of the stream algebra, and
+// the 64 (stream, point) columns of a 16-point tile are exactly two K = 32 steps of the weight-gradient
+// contraction (80 needed three, the last half empty).  Identical to the Cartesian form in exact arithmetic;
+// held to the same oracle / reference tolerances.
+constexpr int NST = 4;
+constexpr int SLP = NST - 1;   // index of the Laplacian stream
+
 // position of neuron slot (kc, g, j) of a B fragment: lane group g holds, as element j of
 // k-chunk kc, neuron 32kc + 16(j>>2) + 4g + (j&3)  (= row tile 2kc + (j>>2), register j&3)
 __host__ __device__ constexpr int slot_neuron(int kc, int g, int j)
@@ -189,429 +199,12 @@ __device__ __forceinline__ float row16_sum(float v)  // sum over the 16 points o
     return v;
 }
 
-// ------------------------------------------------------------------ the kernel
-template <int H, int L, int ACT, int NPASS, int MODE>
-__global__ __launch_bounds__(kBlock, 1) void k_trunk_mfma(const float* __restrict__ theta,
-                                                          const __bf16* __restrict__ wpk_g,
-                                                          TrunkArgs A)
-{
-    using C = MCfg<H, L>;
-    using Lay = TrunkLayout<H, L>;
-    constexpr int HT = C::HT, KC = C::KC, NW = C::NW, PITCH = C::PITCH;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __bf16* wpk = reinterpret_cast<__bf16*>(lds_raw);
-    float* small = reinterpret_cast<float*>(lds_raw + (size_t)C::WPK * 2);
-    __bf16* imgs = reinterpret_cast<__bf16*>(lds_raw + (size_t)C::WPK * 2 + C::NSMALL * 4);
-    // small: [0,2H) W0 ; [2H,3H) b0 ; [3H + (l-1)H) b_l ; then wout[H] ; bout
-    float* sW0 = small;
-    float* sb0 = small + 2 * H;
-    float* sbl = small + 3 * H;
-    float* swo = small + 3 * H + NW * H;
-    float* sbo = swo + H;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, c = lane & 15;
-    __bf16* imgY = imgs + (size_t)wave * 2 * C::IMG;
-    __bf16* imgX = imgY + C::IMG;
-
-    // ---- stage weights (bf16, fragment order) and the small fp32 parameters in LDS
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(wpk_g);
-        uint4* dst = reinterpret_cast<uint4*>(wpk);
-        for (int k = threadIdx.x; k < C::WPK / 8; k += kBlock) dst[k] = src[k];
-        for (int k = threadIdx.x; k < 2 * H; k += kBlock) sW0[k] = theta[Lay::W(0) + k];
-        for (int k = threadIdx.x; k < H; k += kBlock) {
-            sb0[k] = theta[Lay::b(0) + k];
-            swo[k] = theta[Lay::Wout + k];
-#pragma unroll
-            for (int l = 1; l < L; l++) sbl[(l - 1) * H + k] = theta[Lay::b(l) + k];
-        }
-        if (threadIdx.x == 0) sbo[0] = theta[Lay::bout];
-        for (int k = lane; k < 2 * C::IMG / 2; k += 64) reinterpret_cast<unsigned*>(imgY)[k] = 0u;
-    }
-    __syncthreads();
-
-    // ---- persistent gradient state
-    f32x4 wacc[NW][HT][HT];   // W_l-bar tiles in q-order (see q_neuron)
-    f32x4 bacc[L][HT];        // b_l-bar, lane-local running sums (this lane's neurons, its point column)
-    f32x4 w0acc[HT][2];       // W_0-bar[:, 0..1]
-    f32x4 woacc[HT];          // wout-bar
-    float acc_bout = 0.f, acc_pde = 0.f, acc_bc1 = 0.f, acc_bc2 = 0.f;
-    if (MODE == MODE_BWD) {
-#pragma unroll
-        for (int l = 0; l < NW; l++)
-#pragma unroll
-            for (int a = 0; a < HT; a++)
-#pragma unroll
-                for (int b = 0; b < HT; b++) wacc[l][a][b] = splat(0.f);
-#pragma unroll
-        for (int l = 0; l < L; l++)
-#pragma unroll
-            for (int a = 0; a < HT; a++) bacc[l][a] = splat(0.f);
-#pragma unroll
-        for (int a = 0; a < HT; a++) { w0acc[a][0] = splat(0.f); w0acc[a][1] = splat(0.f); woacc[a] = splat(0.f); }
-    }
-    float invN1 = A.invN1, invN2 = A.invN2;
-    if (MODE != MODE_FWD && A.bc_counts) {
-        const long long c1 = A.bc_counts[0], c2 = A.bc_counts[1];
-        invN1 = c1 > 0 ? 1.0f / (float)c1 : 0.0f;
-        invN2 = c2 > 0 ? 1.0f / (float)c2 : 0.0f;
-    }
-    const float lead = g == 0 ? 1.0f : 0.0f;  // one lane group per point feeds the per-point sums
-    const int64_t ntile = (A.n + 15) / 16;
-
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntile;
-         tile += (int64_t)gridDim.x * kWavesPerBlock) {
-        const int64_t idx = tile * 16 + c;
-        const bool valid = idx < A.n;
-        const int64_t id = valid ? idx : A.n - 1;
-        const float xv = A.x[id], yv = A.y[id], zv = A.z[id], Rv = A.R[id];
-        const float Ev = A.E[id], gv = A.g[id];
-        float m1 = 0.f, m2 = 0.f;
-        if (MODE != MODE_FWD && A.mask) {
-            const uint8_t mk = A.mask[id];
-            m1 = float(mk & 1);
-            m2 = float((mk >> 1) & 1);
-        }
-        float inA[2][5], ri1, ri2;
-        orbital<float>(xv - Rv, yv, zv, inA[0], ri1);
-        orbital<float>(xv + Rv, yv, zv, inA[1], ri2);
-        const float F = inA[0][0] + A.P * inA[1][0];
-        const float lapF = inA[0][4] + A.P * inA[1][4];
-
-        Tail<float> t;
-        // saved forward state of every pass: the reverse sweeps (pass B first, then pass A) reuse
-        // it, so no pass is evaluated twice
-        u32x4 xbS[NPASS][L - 1][KC][5];   // B fragments of layer l's output streams (inputs of layer l+1)
-        u32x2 svS[NPASS][NW][HT][5];      // saved (h, a_x, a_y, a_z, a_lap) of layers 1..L-1 as bf16
-        float SvT = 0.f, SlT = 0.f;
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ps++) {
-            const bool useB = ps == 1;
-            float in[2][5];
-#pragma unroll
-            for (int s = 0; s < 5; s++) {
-                in[0][s] = useB ? inA[1][s] : inA[0][s];
-                in[1][s] = useB ? inA[0][s] : inA[1][s];
-            }
-            // =========================== forward ===========================
-            u32x4 (&xb)[L - 1][KC][5] = xbS[ps];
-            u32x2 (&sv)[NW][HT][5] = svS[ps];
-            // ---- layer 0 on the VALU (K = 2)
-#pragma unroll
-            for (int jt = 0; jt < HT; jt++) {
-                const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + (16 * jt + 4 * g) * 2);
-                const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + (16 * jt + 4 * g) * 2 + 4);
-                const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb0 + 16 * jt + 4 * g);
-                f32x4 a[5];
-#pragma unroll
-                for (int s = 0; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
-                a[0] += b0;
-                f32x4 s0, s1, s2;
-                act012v<ACT>(a[0], s0, s1, s2);
-                const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
-                f32x4 o[5] = {s0, s1 * a[1], s1 * a[2], s1 * a[3], s1 * a[4] + s2 * q};
-#pragma unroll
-                for (int s = 0; s < 5; s++) {
-                    const u32x2 p = pack4(o[s]);
-                    if (jt & 1) { xb[0][jt >> 1][s][2] = p[0]; xb[0][jt >> 1][s][3] = p[1]; }
-                    else { xb[0][jt >> 1][s][0] = p[0]; xb[0][jt >> 1][s][1] = p[1]; }
-                }
-            }
-            // ---- layers 1..L-1 on the matrix cores
-            float Sv = 0.f, Sl = 0.f;
-#pragma unroll
-            for (int l = 1; l < L; l++) {
-                const __bf16* wf = wpk + (size_t)((l - 1) * 2 + 0) * H * H;
-#pragma unroll
-                for (int jt = 0; jt < HT; jt++) {
-                    f32x4 a[5];
-                    a[0] = *reinterpret_cast<const f32x4*>(sbl + (l - 1) * H + 16 * jt + 4 * g);
-#pragma unroll
-                    for (int s = 1; s < 5; s++) a[s] = splat(0.f);
-#pragma unroll
-                    for (int kc = 0; kc < KC; kc++) {
-                        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wf + ((jt * KC + kc) * 64 + lane) * 8);
-#pragma unroll
-                        for (int s = 0; s < 5; s++) a[s] = mfma(wa, as_frag(xb[l - 1][kc][s]), a[s]);
-                    }
-                    f32x4 s0, s1, s2;
-                    act012v<ACT>(a[0], s0, s1, s2);
-                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
-                    const f32x4 ol = s1 * a[4] + s2 * q;
-                    sv[l - 1][jt][0] = pack4(s0);
-#pragma unroll
-                    for (int s = 1; s < 5; s++) sv[l - 1][jt][s] = pack4(a[s]);
-                    if (l < L - 1) {
-                        f32x4 o[5] = {s0, s1 * a[1], s1 * a[2], s1 * a[3], ol};
-#pragma unroll
-                        for (int s = 0; s < 5; s++) {
-                            const u32x2 p = pack4(o[s]);
-                            if (jt & 1) { xb[l][jt >> 1][s][2] = p[0]; xb[l][jt >> 1][s][3] = p[1]; }
-                            else { xb[l][jt >> 1][s][0] = p[0]; xb[l][jt >> 1][s][1] = p[1]; }
-                        }
-                    } else {
-                        const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 16 * jt + 4 * g);
-                        const f32x4 pv = wo * s0, pl = wo * ol;
-                        Sv += (pv[0] + pv[1]) + (pv[2] + pv[3]);
-                        Sl += (pl[0] + pl[1]) + (pl[2] + pl[3]);
-                    }
-                }
-            }
-            Sv = xg_sum(Sv);
-            Sl = xg_sum(Sl);
-            SvT += (useB ? A.P : 1.0f) * Sv;
-            SlT += (useB ? A.P : 1.0f) * Sl;
-        }
-        {
-            const float N = A.out_scale * SvT + sbo[0];
-            const float lapN = A.out_scale * SlT;
-            tail<float>(N, lapN, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1, m2, A.invN, invN1,
-                        invN2, valid ? 1.0f : 0.0f, t);
-            if (MODE == MODE_FWD) {
-                if (valid && g == 0) {
-                    if (A.psi) A.psi[idx] = t.psi;
-                    if (A.lap) A.lap[idx] = t.lap;
-                    if (A.res) A.res[idx] = t.res;
-                }
-            } else {
-                if (valid && g == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
-                acc_pde += lead * t.l_pde;
-                acc_bc1 += lead * t.l_bc1;
-                acc_bc2 += lead * t.l_bc2;
-                acc_bout += lead * t.Nb;
-            }
-        }
-        if (MODE != MODE_BWD) continue;
-        // =========================== reverse ===========================
-#pragma unroll
-        for (int ps = NPASS - 1; ps >= 0; ps--) {
-            const bool useB = ps == 1;
-            float in[2][5];
-#pragma unroll
-            for (int s = 0; s < 5; s++) {
-                in[0][s] = useB ? inA[1][s] : inA[0][s];
-                in[1][s] = useB ? inA[0][s] : inA[1][s];
-            }
-            u32x4 (&xb)[L - 1][KC][5] = xbS[ps];
-            u32x2 (&sv)[NW][HT][5] = svS[ps];
-            const float pw = useB ? A.P : 1.0f;
-            const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
-            u32x4 yb[KC][5];  // B fragments of the current layer's pre-activation adjoints
-            // ---- last hidden layer: only the value and Laplacian streams feed Lin_out
-#pragma unroll
-            for (int jt = 0; jt < HT; jt++) {
-                const f32x4 h = unpack4(sv[NW - 1][jt][0]);
-                f32x4 a[5];
-#pragma unroll
-                for (int s = 1; s < 5; s++) a[s] = unpack4(sv[NW - 1][jt][s]);
-                f32x4 s1, s2, s3;
-                act123v<ACT>(h, s1, s2, s3);
-                const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
-                const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 16 * jt + 4 * g);
-                woacc[jt] += cv * h + cl * (s1 * a[4] + s2 * q);
-                const f32x4 o0 = cv * wo, ol = cl * wo;
-                const f32x4 u = 2.0f * s2 * ol;
-                f32x4 ab[5];
-                ab[4] = s1 * ol;
-                ab[1] = u * a[1];
-                ab[2] = u * a[2];
-                ab[3] = u * a[3];
-                ab[0] = s1 * o0 + (s2 * a[4] + s3 * q) * ol;
-                bacc[L - 1][jt] += ab[0];
-#pragma unroll
-                for (int s = 0; s < 5; s++) {
-                    const u32x2 p = pack4(ab[s]);
-                    if (jt & 1) { yb[jt >> 1][s][2] = p[0]; yb[jt >> 1][s][3] = p[1]; }
-                    else { yb[jt >> 1][s][0] = p[0]; yb[jt >> 1][s][1] = p[1]; }
-                }
-            }
-#pragma unroll
-            for (int l = L - 1; l >= 1; l--) {
-                // ---- W_l-bar += Y-bar (x) X over this wave's 80 columns, 32 columns per phase
-#pragma unroll
-                for (int ph = 0; ph < 3; ph++) {
-#pragma unroll
-                    for (int sl = 0; sl < 2; sl++) {
-                        const int s = 2 * ph + sl;
-#pragma unroll
-                        for (int kc = 0; kc < KC; kc++) {
-                            const u32x4 zy = s < 5 ? yb[kc][s < 5 ? s : 0] : u32x4{0u, 0u, 0u, 0u};
-                            const u32x4 zx = s < 5 ? xb[l - 1][kc][s < 5 ? s : 0] : u32x4{0u, 0u, 0u, 0u};
-                            *reinterpret_cast<u32x4*>(imgY + (16 * sl + c) * PITCH + 32 * kc + 8 * g) = zy;
-                            *reinterpret_cast<u32x4*>(imgX + (16 * sl + c) * PITCH + 32 * kc + 8 * g) = zx;
-                        }
-                    }
-                    wave_fence();
-                    bf16x8 fx[HT];
-#pragma unroll
-                    for (int it = 0; it < HT; it++) {
-                        const __bf16* p0 = imgX + (8 * g + (c >> 2)) * PITCH + 16 * it + 4 * (c & 3);
-                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)p0);
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(p0 + 4 * PITCH));
-                        fx[it] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    }
-#pragma unroll
-                    for (int jt = 0; jt < HT; jt++) {
-                        const __bf16* p0 = imgY + (8 * g + (c >> 2)) * PITCH + 16 * jt + 4 * (c & 3);
-                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)p0);
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(p0 + 4 * PITCH));
-                        const bf16x8 fy = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                        for (int it = 0; it < HT; it++) wacc[l - 1][jt][it] = mfma(fy, fx[it], wacc[l - 1][jt][it]);
-                    }
-                    wave_fence();
-                }
-                // ---- adjoint of layer l's input, one row tile at a time, then layer l-1's
-                //      activation adjoint for exactly those neurons
-                const __bf16* wb = wpk + (size_t)((l - 1) * 2 + 1) * H * H;
-                u32x4 ybn[KC][5];
-#pragma unroll
-                for (int it = 0; it < HT; it++) {
-                    f32x4 ob[5];
-#pragma unroll
-                    for (int s = 0; s < 5; s++) ob[s] = splat(0.f);
-#pragma unroll
-                    for (int kc = 0; kc < KC; kc++) {
-                        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wb + ((it * KC + kc) * 64 + lane) * 8);
-#pragma unroll
-                        for (int s = 0; s < 5; s++) ob[s] = mfma(wa, as_frag(yb[kc][s]), ob[s]);
-                    }
-                    f32x4 h, a[5];
-                    if (l - 1 == 0) {  // recompute layer 0's derivative streams (K = 2); h from its bf16 output
-                        const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + (16 * it + 4 * g) * 2);
-                        const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + (16 * it + 4 * g) * 2 + 4);
-                        const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
-#pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
-                        const u32x4 hx = xb[0][it >> 1][0];
-                        h = unpack4((it & 1) ? u32x2{hx[2], hx[3]} : u32x2{hx[0], hx[1]});
-                    } else {
-                        h = unpack4(sv[l - 2][it][0]);
-#pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[l - 2][it][s]);
-                    }
-                    f32x4 s1, s2, s3;
-                    act123v<ACT>(h, s1, s2, s3);
-                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
-                    const f32x4 u = 2.0f * s2 * ob[4];
-                    f32x4 ab[5];
-                    ab[4] = s1 * ob[4];
-                    ab[1] = s1 * ob[1] + u * a[1];
-                    ab[2] = s1 * ob[2] + u * a[2];
-                    ab[3] = s1 * ob[3] + u * a[3];
-                    ab[0] = s1 * ob[0] + s2 * (a[1] * ob[1] + a[2] * ob[2] + a[3] * ob[3]) +
-                            (s2 * a[4] + s3 * q) * ob[4];
-                    bacc[l - 1][it] += ab[0];
-                    if (l - 1 == 0) {
-                        f32x4 g0 = splat(0.f), g1 = splat(0.f);
-#pragma unroll
-                        for (int s = 0; s < 5; s++) { g0 += ab[s] * in[0][s]; g1 += ab[s] * in[1][s]; }
-                        w0acc[it][0] += g0;
-                        w0acc[it][1] += g1;
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < 5; s++) {
-                            const u32x2 p = pack4(ab[s]);
-                            if (it & 1) { ybn[it >> 1][s][2] = p[0]; ybn[it >> 1][s][3] = p[1]; }
-                            else { ybn[it >> 1][s][0] = p[0]; ybn[it >> 1][s][1] = p[1]; }
-                        }
-                    }
-                }
-                if (l - 1 >= 1) {
-#pragma unroll
-                    for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-                        for (int s = 0; s < 5; s++) yb[kc][s] = ybn[kc][s];
-                }
-            }
-        }
-    }
-
-    if (MODE == MODE_FWD) return;
-    // =========================== block reduction ===========================
-    __syncthreads();  // images are dead; reuse the LDS front (weights) as the gradient image
-    constexpr int PT = Lay::size;
-    float* gimg = reinterpret_cast<float*>(lds_raw);  // PT floats + 4 scalars
-    float* sc = gimg + PT;
-    const float s0 = row16_sum(xg_sum(acc_pde)), s1r = row16_sum(xg_sum(acc_bc1)),
-                s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
-    // lane-local vector sums -> per (g, neuron) totals over the 16 point columns
-    if (MODE == MODE_BWD) {
-#pragma unroll
-        for (int jt = 0; jt < HT; jt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-#pragma unroll
-                for (int l = 0; l < L; l++) bacc[l][jt][r] = row16_sum(bacc[l][jt][r]);
-                w0acc[jt][0][r] = row16_sum(w0acc[jt][0][r]);
-                w0acc[jt][1][r] = row16_sum(w0acc[jt][1][r]);
-                woacc[jt][r] = row16_sum(woacc[jt][r]);
-            }
-    }
-    for (int w = 0; w < kWavesPerBlock; w++) {
-        if (wave == w) {
-            const bool add = w != 0;
-            if (MODE == MODE_BWD) {
-#pragma unroll
-                for (int l = 1; l < L; l++)
-#pragma unroll
-                    for (int jt = 0; jt < HT; jt++)
-#pragma unroll
-                        for (int it = 0; it < HT; it++)
-#pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const int nj = q_neuron(16 * jt + 4 * g + r), ni = q_neuron(16 * it + c);
-                                float* p = gimg + Lay::W(l) + nj * H + ni;
-                                *p = add ? *p + wacc[l - 1][jt][it][r] : wacc[l - 1][jt][it][r];
-                            }
-                if (c == 0) {
-#pragma unroll
-                    for (int jt = 0; jt < HT; jt++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int nj = 16 * jt + 4 * g + r;
-#pragma unroll
-                            for (int l = 0; l < L; l++) {
-                                float* p = gimg + Lay::b(l) + nj;
-                                *p = add ? *p + bacc[l][jt][r] : bacc[l][jt][r];
-                            }
-                            float* p0 = gimg + Lay::W(0) + 2 * nj;
-                            p0[0] = add ? p0[0] + w0acc[jt][0][r] : w0acc[jt][0][r];
-                            p0[1] = add ? p0[1] + w0acc[jt][1][r] : w0acc[jt][1][r];
-                            float* po = gimg + Lay::Wout + nj;
-                            *po = add ? *po + woacc[jt][r] : woacc[jt][r];
-                        }
-                }
-            }
-            if (lane == 0) {
-                if (!add) { sc[0] = s0; sc[1] = s1r; sc[2] = s2r; sc[3] = s3r; }
-                else { sc[0] += s0; sc[1] += s1r; sc[2] += s2r; sc[3] += s3r; }
-            }
-        }
-        __syncthreads();
-    }
-    float* out = A.partial + (size_t)blockIdx.x * A.stride;
-    if (MODE == MODE_BWD) {
-        for (int k = threadIdx.x; k < PT; k += kBlock) out[k] = k == Lay::bout ? sc[3] : gimg[k];
-    } else {
-        for (int k = threadIdx.x; k < PT; k += kBlock) out[k] = 0.0f;
-    }
-    if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
-}
-
 // =====================================================================================
 // Second generation: the 16-point tile of a "group" is shared by SPLIT waves, each owning
 // 32 neurons (two row tiles = one k-chunk).  Per-wave state shrinks by SPLIT, so H = 64 runs
 // two waves per SIMD (latency hiding) and H = 128 fits at all.  Waves of a group exchange
 // B fragments (layer outputs, adjoints) through LDS exchange buffers
-//     EB[(kc*5 + s)*64 + lane]   (16 bytes per lane, lane-linear: conflict-free b128)
+//     EB[(kc*NST + s)*64 + lane]   (16 bytes per lane, lane-linear: conflict-free b128)
 // which every wave of the group reads directly as MFMA B operands, and which double as the
 // [column][neuron] image of the weight-gradient contraction (ds_read_b64_tr_b16 straight
 // from the exchange buffer: no extra image writes).  Workgroup barriers separate the
@@ -653,10 +246,10 @@ struct M2Cfg {
     // instructions less per row tile and pass) where the registers are there; bf16 pairs otherwise
     static constexpr bool SVF32 = X3 || (H == 64 && L == 2);
     static constexpr int NSMALL = 3 * H + NW * H + H + 4;         // floats
-    static constexpr int EB1 = KC * 5 * 64 * 16;                  // bytes of one plane of an exchange buffer
+    static constexpr int EB1 = KC * NST * 64 * 16;                // bytes of one plane of an exchange buffer
     static constexpr int EB = NPL * EB1;
     static constexpr int SBYTES = SPLIT * 16 * 2 * 4;             // per-group partial (Sv, Sl)
-    static constexpr int ZBYTES = 1024;
+    static constexpr int ZBYTES = 0;
     static constexpr size_t OFF_SMALL = (size_t)WPK * 2;
     static constexpr size_t OFF_ZERO = OFF_SMALL + NSMALL * 4;
     static constexpr size_t OFF_GRP = OFF_ZERO + ZBYTES;
@@ -691,7 +284,6 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
     // LDS addresses are 32-bit: every access below is (uniform base) + (one lane register) + immediate
     typedef __attribute__((address_space(3))) unsigned char* lds_p;
     const lds_p lds0 = (lds_p)lds_raw;
-    const lds_p zero = lds0 + C::OFF_ZERO;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -710,10 +302,9 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
     // transposed-read lane offset: row (8g + 4hh + (c>>2)) -> stream half (g>>1), point 8(g&1)+(c>>2);
     // 8-byte piece (c&1) of chunk ((c&3)>>1) of the tile: everything else is an immediate
     const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
-    const bool padlane = g >= 2;                        // phase 2 has no sixth stream: those lanes read zeros
     // this wave's piece of B fragment (k-chunk, stream s): all 16 bytes (RT = 2) or one 8-byte half
     const int own_kc = (RT * part) >> 1, own_half = (RT * part) & 1;
-    const int own_slot = lane16 + own_kc * 5 * 64 * 16 + 8 * own_half;   // byte offset of the own piece
+    const int own_slot = lane16 + own_kc * NST * 64 * 16 + 8 * own_half;   // byte offset of the own piece
     auto put_own = [&](lds_p eb, int s, const u32x4& v) {
         const lds_p p = eb + own_slot + s * 64 * 16;
         if (RT == 2) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(p) = v;
@@ -754,8 +345,6 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
             for (int l = 1; l < L; l++) sbl[(l - 1) * H + k] = theta[Lay::b(l) + k];
         }
         if (threadIdx.x == 0) sbo[0] = theta[Lay::bout];
-        for (int k = threadIdx.x; k < C::ZBYTES / 4; k += NT)
-            reinterpret_cast<unsigned*>(lds_raw + C::OFF_ZERO)[k] = 0u;
     }
     const __bf16* wsrc = (C::WLDS || C::WHI) ? wpk : wpk_g;   // one provenance per instantiation
     // lo plane: behind the hi plane in the same image, or (WHI, WSTREAM) in global memory
@@ -809,39 +398,51 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
     const int64_t tstride = (int64_t)gridDim.x * C::GROUPS;
     const int64_t iters = (ntile + tstride - 1) / tstride;   // same for every wave: barriers match
 
+    // the point record of the NEXT tile is requested one trip ahead (7 loads per lane that nothing waits
+    // for until the next trip): without this every trip opened with an exposed round trip to L2/HBM
+    struct PointRec { float x, y, z, R, E, g; unsigned mk; };
+    auto load_rec = [&](int64_t itn) {
+        const int64_t tl = itn * tstride + (int64_t)blockIdx.x * C::GROUPS + grp;
+        int64_t id = tl * 16 + c;
+        id = (tl < ntile && id < A.n) ? id : A.n - 1;
+        PointRec r;
+        r.x = A.x[id]; r.y = A.y[id]; r.z = A.z[id]; r.R = A.R[id]; r.E = A.E[id]; r.g = A.g[id];
+        r.mk = (MODE != MODE_FWD && A.mask) ? A.mask[id] : 0u;
+        return r;
+    };
+    PointRec nxt = load_rec(0);
     for (int64_t itx = 0; itx < iters; itx++) {
         const int64_t tile = itx * tstride + (int64_t)blockIdx.x * C::GROUPS + grp;
         const int64_t idx = tile * 16 + c;
         const bool valid = tile < ntile && idx < A.n;
-        const int64_t id = valid ? idx : A.n - 1;
-        const float xv = A.x[id], yv = A.y[id], zv = A.z[id], Rv = A.R[id];
-        const float Ev = A.E[id], gv = A.g[id];
-        float m1 = 0.f, m2 = 0.f;
-        if (MODE != MODE_FWD && A.mask) {
-            const uint8_t mk = A.mask[id];
-            m1 = float(mk & 1);
-            m2 = float((mk >> 1) & 1);
+        const PointRec cur = nxt;
+        if (itx + 1 < iters) nxt = load_rec(itx + 1);
+        const float xv = cur.x, yv = cur.y, zv = cur.z, Rv = cur.R;
+        const float Ev = cur.E, gv = cur.g;
+        const float m1 = float(cur.mk & 1), m2 = float((cur.mk >> 1) & 1);
+        float inA[2][NST], ri1, ri2;
+        {
+            const float rho2 = yv * yv + zv * zv, rho = __builtin_amdgcn_sqrtf(rho2);
+            orbital_cyl<float>(xv - Rv, rho2, rho, inA[0], ri1);
+            orbital_cyl<float>(xv + Rv, rho2, rho, inA[1], ri2);
         }
-        float inA[2][5], ri1, ri2;
-        orbital<float>(xv - Rv, yv, zv, inA[0], ri1);
-        orbital<float>(xv + Rv, yv, zv, inA[1], ri2);
         const float F = inA[0][0] + A.P * inA[1][0];
-        const float lapF = inA[0][4] + A.P * inA[1][4];
+        const float lapF = inA[0][SLP] + A.P * inA[1][SLP];
 
         Tail<float> t;
         // saved forward state per pass slot: (h, a_x, a_y, a_z, a_lap) of the own neurons, layers
         // 1..L-1, as fp32 or bf16 pairs (C::SVF32; always fp32 in split-bf16 mode: the adjoint algebra
         // must not be the precision bottleneck) and the layer-0 activation.  With KEEP both passes keep their own
         // slot (and their own XB buffers in LDS), so no pass is evaluated twice.
-        u32x2 sv[NS][SVF ? 1 : NW][RT][5];
-        f32x4 svf[NS][SVF ? NW : 1][RT][5];
+        u32x2 sv[NS][SVF ? 1 : NW][RT][NST];
+        f32x4 svf[NS][SVF ? NW : 1][RT][NST];
         f32x4 h0[NS][RT];
         auto fwd = [&](const bool useB, auto SLc, float& Sv, float& Sl, const int wnext) {
             constexpr int SL = decltype(SLc)::value;
             const lds_p XBs = XB + SL * NXL * C::EB;
-            float in[2][5];
+            float in[2][NST];
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < NST; s++) {
                 in[0][s] = useB ? inA[1][s] : inA[0][s];
                 in[1][s] = useB ? inA[0][s] : inA[1][s];
             }
@@ -849,7 +450,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
             // saved (h, a_x, a_y, a_z, a_lap) of the own neurons, layers 1..L-1: bf16 pairs, or
             // fp32 in split-bf16 mode (the adjoint algebra must not be the precision bottleneck)
             {   // ---- layer 0 on the VALU (K = 2), own neurons only
-                f32x4 o[5][RT];
+                f32x4 o[NST][RT];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
                     const int n0 = 16 * (RT * part + tt) + 4 * g;
@@ -857,22 +458,21 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2 + 4);
                     const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
                     const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb0 + n0);
-                    f32x4 a[5];
+                    f32x4 a[NST];
 #pragma unroll
-                    for (int s = 0; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
+                    for (int s = 0; s < NST; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
                     a[0] += b0;
                     f32x4 s0, s1, s2;
                     act012v<ACT>(a[0], s0, s1, s2);
-                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                    const f32x4 q = a[1] * a[1] + a[2] * a[2];
                     o[0][tt] = s0;
                     o[1][tt] = s1 * a[1];
                     o[2][tt] = s1 * a[2];
-                    o[3][tt] = s1 * a[3];
-                    o[4][tt] = s1 * a[4] + s2 * q;
+                    o[SLP][tt] = s1 * a[SLP] + s2 * q;
                     h0[SL][tt] = s0;
                 }
 #pragma unroll
-                for (int s = 0; s < 5; s++) put_split(XBs, s, o[s]);
+                for (int s = 0; s < NST; s++) put_split(XBs, s, o[s]);
             }
             __syncthreads();
             Sv = 0.f; Sl = 0.f;
@@ -882,22 +482,22 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                 const __bf16* wf = WSTREAM ? wcur() : wsrc + (size_t)((l - 1) * 2 + 0) * H * H;
                 const __bf16* wfl = wlo_f + (size_t)((l - 1) * 2 + 0) * H * H;   // lo plane of the same matrix
                 const lds_p xin = XBs + (XONE ? 0 : l - 1) * C::EB + lane16;
-                f32x4 a[RT][5];
+                f32x4 a[RT][NST];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
                     a[tt][0] = *reinterpret_cast<const f32x4*>(sbl + (l - 1) * H + 16 * (RT * part + tt) + 4 * g);
 #pragma unroll
-                    for (int s = 1; s < 5; s++) a[tt][s] = splat(0.f);
+                    for (int s = 1; s < NST; s++) a[tt][s] = splat(0.f);
                 }
                 if constexpr (C::PIPE) {
-                    bf16x8 wq[2][RT], xq[2][5];
-                    auto fetch = [&](int kc, bf16x8 (&w)[RT], bf16x8 (&x)[5]) {
+                    bf16x8 wq[2][RT], xq[2][NST];
+                    auto fetch = [&](int kc, bf16x8 (&w)[RT], bf16x8 (&x)[NST]) {
 #pragma unroll
                         for (int tt = 0; tt < RT; tt++)
                             w[tt] = *reinterpret_cast<const bf16x8*>(wf + (((RT * part + tt) * KC + kc) * 64 + lane) * 8);
 #pragma unroll
-                        for (int s = 0; s < 5; s++)
-                            x[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(xin + (kc * 5 + s) * 64 * 16);
+                        for (int s = 0; s < NST; s++)
+                            x[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(xin + (kc * NST + s) * 64 * 16);
                     };
                     fetch(0, wq[0], xq[0]);
 #pragma unroll
@@ -905,7 +505,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                         if (kc + 1 < KC) fetch(kc + 1, wq[(kc + 1) & 1], xq[(kc + 1) & 1]);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int s = 0; s < 5; s++)
+                        for (int s = 0; s < NST; s++)
 #pragma unroll
                             for (int tt = 0; tt < RT; tt++) a[tt][s] = mfma(wq[kc & 1][tt], xq[kc & 1][s], a[tt][s]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -921,8 +521,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                         wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(wfl + fo) : wa[tt];
                     }
 #pragma unroll
-                    for (int s = 0; s < 5; s++) {
-                        const lds_p px = xin + (kc * 5 + s) * 64 * 16;
+                    for (int s = 0; s < NST; s++) {
+                        const lds_p px = xin + (kc * NST + s) * 64 * 16;
                         const bf16x8 xb = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(px);
                         const bf16x8 xl = X3 ? *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(px + EB1) : xb;
 #pragma unroll
@@ -930,28 +530,27 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     }
                 }
                 }
-                f32x4 o[5][RT];
+                f32x4 o[NST][RT];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
                     f32x4 s0, s1, s2;
                     act012v<ACT>(a[tt][0], s0, s1, s2);
-                    const f32x4 q = a[tt][1] * a[tt][1] + a[tt][2] * a[tt][2] + a[tt][3] * a[tt][3];
-                    const f32x4 ol = s1 * a[tt][4] + s2 * q;
+                    const f32x4 q = a[tt][1] * a[tt][1] + a[tt][2] * a[tt][2];
+                    const f32x4 ol = s1 * a[tt][SLP] + s2 * q;
                     if constexpr (SVF) {
                         svf[SL][l - 1][tt][0] = s0;
 #pragma unroll
-                        for (int s = 1; s < 5; s++) svf[SL][l - 1][tt][s] = a[tt][s];
+                        for (int s = 1; s < NST; s++) svf[SL][l - 1][tt][s] = a[tt][s];
                     } else {
                         sv[SL][l - 1][tt][0] = pack4(s0);
 #pragma unroll
-                        for (int s = 1; s < 5; s++) sv[SL][l - 1][tt][s] = pack4(a[tt][s]);
+                        for (int s = 1; s < NST; s++) sv[SL][l - 1][tt][s] = pack4(a[tt][s]);
                     }
                     if (l < L - 1) {
                         o[0][tt] = s0;
                         o[1][tt] = s1 * a[tt][1];
                         o[2][tt] = s1 * a[tt][2];
-                        o[3][tt] = s1 * a[tt][3];
-                        o[4][tt] = ol;
+                        o[SLP][tt] = ol;
                     } else {
                         const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 16 * (RT * part + tt) + 4 * g);
                         const f32x4 pv = wo * s0, pl = wo * ol;
@@ -963,7 +562,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     const lds_p xout = XBs + (XONE ? 0 : l) * C::EB;
                     if (XONE) __syncthreads();   // one buffer: everyone is done reading layer l-1's outputs
 #pragma unroll
-                    for (int s = 0; s < 5; s++) put_split(xout, s, o[s]);
+                    for (int s = 0; s < NST; s++) put_split(xout, s, o[s]);
                     __syncthreads();
                 }
                 if (WSTREAM) wuse++;
@@ -980,9 +579,9 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
         auto rev = [&](const bool useB, auto SLc, const int wnext) {
             constexpr int SL = decltype(SLc)::value;
             const lds_p XBs = XB + SL * NXL * C::EB;
-            float in[2][5];
+            float in[2][NST];
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < NST; s++) {
                 in[0][s] = useB ? inA[1][s] : inA[0][s];
                 in[1][s] = useB ? inA[0][s] : inA[1][s];
             }
@@ -990,50 +589,49 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
             const float pw = useB ? A.P : 1.0f;
             const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
             {   // ---- last hidden layer, own neurons
-                f32x4 yo[5][RT];
+                f32x4 yo[NST][RT];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
-                    f32x4 h, a[5];
+                    f32x4 h, a[NST];
                     if constexpr (SVF) {
                         h = svf[SL][NW - 1][tt][0];
 #pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = svf[SL][NW - 1][tt][s];
+                        for (int s = 1; s < NST; s++) a[s] = svf[SL][NW - 1][tt][s];
                     } else {
                         h = unpack4(sv[SL][NW - 1][tt][0]);
 #pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[SL][NW - 1][tt][s]);
+                        for (int s = 1; s < NST; s++) a[s] = unpack4(sv[SL][NW - 1][tt][s]);
                     }
                     f32x4 s1, s2, s3;
                     act123v<ACT>(h, s1, s2, s3);
-                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                    const f32x4 q = a[1] * a[1] + a[2] * a[2];
                     const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + 16 * (RT * part + tt) + 4 * g);
-                    woacc[tt] += cv * h + cl * (s1 * a[4] + s2 * q);
+                    woacc[tt] += cv * h + cl * (s1 * a[SLP] + s2 * q);
                     const f32x4 o0 = cv * wo, ol = cl * wo;
                     const f32x4 u = 2.0f * s2 * ol;
-                    yo[4][tt] = s1 * ol;
+                    yo[SLP][tt] = s1 * ol;
                     yo[1][tt] = u * a[1];
                     yo[2][tt] = u * a[2];
-                    yo[3][tt] = u * a[3];
-                    yo[0][tt] = s1 * o0 + (s2 * a[4] + s3 * q) * ol;
+                    yo[0][tt] = s1 * o0 + (s2 * a[SLP] + s3 * q) * ol;
                     bacc[L - 1][tt] += yo[0][tt];
                 }
 #pragma unroll
-                for (int s = 0; s < 5; s++) put_split(YB, s, yo[s]);
+                for (int s = 0; s < NST; s++) put_split(YB, s, yo[s]);
             }
             __syncthreads();
 #pragma unroll
             for (int l = L - 1; l >= 1; l--) {
                 const lds_p xin = XBs + (XONE ? 0 : l - 1) * C::EB;
                 wstage(l - 1 >= 1 ? (l - 2) * 2 + 1 : wnext, wuse + 1);
-                // ---- W_l-bar[own rows][all columns] += Y-bar (x) X, 32 of the 80 columns per phase,
-                //      both operands read transposed straight out of the exchange buffers
+                // ---- W_l-bar[own rows][all columns] += Y-bar (x) X, 32 of the 64 (stream, point) columns per
+                //      phase, both operands read transposed straight out of the exchange buffers
 #pragma unroll
-                for (int ph = 0; ph < 3; ph++) {
+                for (int ph = 0; ph < NST / 2; ph++) {
                     // rows k = 8g + 4hh + (c>>2) of the phase: stream 2ph + (k>>4), point k&15
                     auto frag = [&](lds_p base, int T, int plane) {
-                        const int imm = ph * 2048 + (T >> 1) * 5 * 64 * 16 + (T & 1) * 512 + plane * EB1;
-                        const lds_p p0 = (ph == 2 && padlane) ? zero : base + trl + imm;
-                        const lds_p p1 = (ph == 2 && padlane) ? zero : base + trl + imm + 64;
+                        const int imm = ph * 2048 + (T >> 1) * NST * 64 * 16 + (T & 1) * 512 + plane * EB1;
+                        const lds_p p0 = base + trl + imm;
+                        const lds_p p1 = base + trl + imm + 64;
                         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
                         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
                         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -1070,20 +668,20 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                 // ---- adjoint of layer l's input for the own neurons, then layer l-1's activation adjoint
                 const __bf16* wb = WSTREAM ? wcur() : wsrc + (size_t)((l - 1) * 2 + 1) * H * H;
                 const __bf16* wbl = wlo_f + (size_t)((l - 1) * 2 + 1) * H * H;
-                f32x4 ob[RT][5];
+                f32x4 ob[RT][NST];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++)
 #pragma unroll
-                    for (int s = 0; s < 5; s++) ob[tt][s] = splat(0.f);
+                    for (int s = 0; s < NST; s++) ob[tt][s] = splat(0.f);
                 if constexpr (C::PIPE) {
-                    bf16x8 wq[2][RT], yq[2][5];
-                    auto fetch = [&](int kc, bf16x8 (&w)[RT], bf16x8 (&y)[5]) {
+                    bf16x8 wq[2][RT], yq[2][NST];
+                    auto fetch = [&](int kc, bf16x8 (&w)[RT], bf16x8 (&y)[NST]) {
 #pragma unroll
                         for (int tt = 0; tt < RT; tt++)
                             w[tt] = *reinterpret_cast<const bf16x8*>(wb + (((RT * part + tt) * KC + kc) * 64 + lane) * 8);
 #pragma unroll
-                        for (int s = 0; s < 5; s++)
-                            y[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(YB + lane16 + (kc * 5 + s) * 64 * 16);
+                        for (int s = 0; s < NST; s++)
+                            y[s] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(YB + lane16 + (kc * NST + s) * 64 * 16);
                     };
                     fetch(0, wq[0], yq[0]);
 #pragma unroll
@@ -1091,7 +689,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                         if (kc + 1 < KC) fetch(kc + 1, wq[(kc + 1) & 1], yq[(kc + 1) & 1]);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int s = 0; s < 5; s++)
+                        for (int s = 0; s < NST; s++)
 #pragma unroll
                             for (int tt = 0; tt < RT; tt++) ob[tt][s] = mfma(wq[kc & 1][tt], yq[kc & 1][s], ob[tt][s]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -1107,8 +705,8 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                         wl[tt] = X3 ? *reinterpret_cast<const bf16x8*>(wbl + fo) : wa[tt];
                     }
 #pragma unroll
-                    for (int s = 0; s < 5; s++) {
-                        const lds_p py = YB + lane16 + (kc * 5 + s) * 64 * 16;
+                    for (int s = 0; s < NST; s++) {
+                        const lds_p py = YB + lane16 + (kc * NST + s) * 64 * 16;
                         const bf16x8 yb = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(py);
                         const bf16x8 yl = X3 ? *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(py + EB1) : yb;
 #pragma unroll
@@ -1116,85 +714,83 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                     }
                 }
                 }
-                f32x4 yo[5][RT];
+                f32x4 yo[NST][RT];
 #pragma unroll
                 for (int tt = 0; tt < RT; tt++) {
-                    f32x4 h, a[5];
+                    f32x4 h, a[NST];
                     if (l - 1 == 0) {
                         const int n0 = 16 * (RT * part + tt) + 4 * g;
                         const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2);
                         const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2 + 4);
                         const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
 #pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
+                        for (int s = 1; s < NST; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
                         h = h0[SL][tt];
                     } else if constexpr (SVF) {
                         h = svf[SL][l - 2][tt][0];
 #pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = svf[SL][l - 2][tt][s];
+                        for (int s = 1; s < NST; s++) a[s] = svf[SL][l - 2][tt][s];
                     } else {
                         h = unpack4(sv[SL][l - 2][tt][0]);
 #pragma unroll
-                        for (int s = 1; s < 5; s++) a[s] = unpack4(sv[SL][l - 2][tt][s]);
+                        for (int s = 1; s < NST; s++) a[s] = unpack4(sv[SL][l - 2][tt][s]);
                     }
                     f32x4 s1, s2, s3;
                     act123v<ACT>(h, s1, s2, s3);
-                    const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
-                    const f32x4 u = 2.0f * s2 * ob[tt][4];
-                    f32x4 ab[5];
-                    ab[4] = s1 * ob[tt][4];
+                    const f32x4 q = a[1] * a[1] + a[2] * a[2];
+                    const f32x4 u = 2.0f * s2 * ob[tt][SLP];
+                    f32x4 ab[NST];
+                    ab[SLP] = s1 * ob[tt][SLP];
                     ab[1] = s1 * ob[tt][1] + u * a[1];
                     ab[2] = s1 * ob[tt][2] + u * a[2];
-                    ab[3] = s1 * ob[tt][3] + u * a[3];
-                    ab[0] = s1 * ob[tt][0] + s2 * (a[1] * ob[tt][1] + a[2] * ob[tt][2] + a[3] * ob[tt][3]) +
-                            (s2 * a[4] + s3 * q) * ob[tt][4];
+                    ab[0] = s1 * ob[tt][0] + s2 * (a[1] * ob[tt][1] + a[2] * ob[tt][2]) +
+                            (s2 * a[SLP] + s3 * q) * ob[tt][SLP];
                     bacc[l - 1][tt] += ab[0];
                     if (l - 1 == 0) {
                         f32x4 g0 = splat(0.f), g1 = splat(0.f);
 #pragma unroll
-                        for (int s = 0; s < 5; s++) { g0 += ab[s] * in[0][s]; g1 += ab[s] * in[1][s]; }
+                        for (int s = 0; s < NST; s++) { g0 += ab[s] * in[0][s]; g1 += ab[s] * in[1][s]; }
                         w0acc[tt][0] += g0;
                         w0acc[tt][1] += g1;
                     } else {
 #pragma unroll
-                        for (int s = 0; s < 5; s++) yo[s][tt] = ab[s];
+                        for (int s = 0; s < NST; s++) yo[s][tt] = ab[s];
                     }
                 }
                 if (l - 1 >= 1) {   // hand the next layer's adjoints to the group
                     __syncthreads();   // everyone is done reading YB (and, XONE, the layer-output buffer)
 #pragma unroll
-                    for (int s = 0; s < 5; s++) put_split(YB, s, yo[s]);
+                    for (int s = 0; s < NST; s++) put_split(YB, s, yo[s]);
                     if constexpr (XONE) {
                         // the next weight gradient (layer l-1) contracts with the outputs of layer l-2:
                         // rebuild them from that layer's saved state into the one layer-output buffer
-                        f32x4 xo[5][RT];
+                        f32x4 xo[NST][RT];
 #pragma unroll
                         for (int tt = 0; tt < RT; tt++) {
-                            f32x4 h, a[5];
+                            f32x4 h, a[NST];
                             if (l - 2 == 0) {
                                 const int n0 = 16 * (RT * part + tt) + 4 * g;
                                 const f32x4 wA = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2);
                                 const f32x4 wB = *reinterpret_cast<const f32x4*>(sW0 + n0 * 2 + 4);
                                 const f32x4 w0 = {wA[0], wA[2], wB[0], wB[2]}, w1 = {wA[1], wA[3], wB[1], wB[3]};
 #pragma unroll
-                                for (int s = 1; s < 5; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
+                                for (int s = 1; s < NST; s++) a[s] = w0 * in[0][s] + w1 * in[1][s];
                                 h = h0[SL][tt];
                             } else {
                                 h = svf[SL][l - 3 >= 0 ? l - 3 : 0][tt][0];
 #pragma unroll
-                                for (int s = 1; s < 5; s++) a[s] = svf[SL][l - 3 >= 0 ? l - 3 : 0][tt][s];
+                                for (int s = 1; s < NST; s++) a[s] = svf[SL][l - 3 >= 0 ? l - 3 : 0][tt][s];
                             }
                             f32x4 s1, s2, s3;
                             act123v<ACT>(h, s1, s2, s3);
-                            const f32x4 q = a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+                            const f32x4 q = a[1] * a[1] + a[2] * a[2];
                             xo[0][tt] = h;
                             xo[1][tt] = s1 * a[1];
                             xo[2][tt] = s1 * a[2];
-                            xo[3][tt] = s1 * a[3];
-                            xo[4][tt] = s1 * a[4] + s2 * q;
+                            xo[SLP][tt] = s1 * a[SLP] + s2 * q;
                         }
 #pragma unroll
-                        for (int s = 0; s < 5; s++) put_split(XBs, s, xo[s]);
+                        for (int s = 0; s < NST; s++) put_split(XBs, s, xo[s]);
                     }
                     __syncthreads();
                 }
@@ -1408,45 +1004,6 @@ bool launch2_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, c
     PINN_MCASE2(ACT_TANH, 2, MODE_FWD) PINN_MCASE2(ACT_TANH, 2, MODE_BWD) PINN_MCASE2(ACT_TANH, 2, MODE_HEAD)
     PINN_MCASE2(ACT_TANH, 1, MODE_FWD) PINN_MCASE2(ACT_TANH, 1, MODE_BWD) PINN_MCASE2(ACT_TANH, 1, MODE_HEAD)
 #undef PINN_MCASE2
-    return false;
-}
-
-template <int H, int L, int ACT, int NPASS, int MODE>
-hipError_t launch_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
-{
-    using C = MCfg<H, L>;
-    const int nfrag = C::NW * 2 * C::HT * C::KC * 64;
-    hipLaunchKernelGGL((k_pack_weights<H, L>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    auto kern = k_trunk_mfma<H, L, ACT, NPASS, MODE>;
-    size_t lds = C::LDS_BYTES;
-    const size_t need = (size_t)(TrunkLayout<H, L>::size + 16) * 4;
-    if (lds < need) lds = need;
-    static bool attr_set = false;   // once per instantiation: not a stream operation (graph capture)
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, theta, (const __bf16*)wpk, A);
-    return hipGetLastError();
-}
-
-template <int H, int L>
-bool launch_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, const TrunkArgs& A,
-               int grid, hipStream_t st, hipError_t* e)
-{
-#define PINN_MCASE(ACT, NP, MD)                                            \
-    if (act == ACT && npass == NP && mode == MD) {                         \
-        *e = launch_t<H, L, ACT, NP, MD>(theta, wpk, A, grid, st);         \
-        return true;                                                       \
-    }
-    PINN_MCASE(ACT_SIGMOID, 2, MODE_FWD) PINN_MCASE(ACT_SIGMOID, 2, MODE_BWD)
-    PINN_MCASE(ACT_SIGMOID, 1, MODE_FWD) PINN_MCASE(ACT_SIGMOID, 1, MODE_BWD)
-    PINN_MCASE(ACT_TANH, 2, MODE_FWD) PINN_MCASE(ACT_TANH, 2, MODE_BWD)
-    PINN_MCASE(ACT_TANH, 1, MODE_FWD) PINN_MCASE(ACT_TANH, 1, MODE_BWD)
-#undef PINN_MCASE
     return false;
 }
 
@@ -1819,7 +1376,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
     using Lay = TrunkLayout<16, 2>;
     constexpr int PT = Lay::size;
     constexpr int PITCH = 24;                 // bf16 per image row: 16 neurons + 8
-    constexpr int IMG = 5 * 16 * PITCH;       // one image: 5 streams x 16 points
+    constexpr int IMG = NST * 16 * PITCH;     // one image: NST streams x 16 points
     __shared__ __attribute__((aligned(16))) __bf16 imgs[(MODE == MODE_BWD ? kWavesPerBlock * 4 * IMG : 8)];
     __shared__ float gimg[PT + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
@@ -1880,45 +1437,47 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             m1 = float(mk & 1);
             m2 = float((mk >> 1) & 1);
         }
-        float inA[2][5], ri1, ri2;
-        orbital<float>(xv - Rv, yv, zv, inA[0], ri1);
-        orbital<float>(xv + Rv, yv, zv, inA[1], ri2);
+        float inA[2][NST], ri1, ri2;
+        {
+            const float rho2 = yv * yv + zv * zv, rho = __builtin_amdgcn_sqrtf(rho2);
+            orbital_cyl<float>(xv - Rv, rho2, rho, inA[0], ri1);
+            orbital_cyl<float>(xv + Rv, rho2, rho, inA[1], ri2);
+        }
         const float F = inA[0][0] + A.P * inA[1][0];
-        const float lapF = inA[0][4] + A.P * inA[1][4];
+        const float lapF = inA[0][SLP] + A.P * inA[1][SLP];
 
         // saved forward state per pass: the layer-0 output streams as their two leading bf16 pieces
         // (exactly the X operand of the weight gradient), the layer-0 activation in fp32, and
-        // (h, a_x, a_y, a_z, a_lap) of layer 1
-        u32x2 xh[NPASS][5], xl[NPASS][5];
-        f32x4 h0s[NPASS], sv[NPASS][5];
+        // (h, a_x, a_rho, a_lap) of layer 1
+        u32x2 xh[NPASS][NST], xl[NPASS][NST];
+        f32x4 h0s[NPASS], sv[NPASS][NST];
         float SvT = 0.f, SlT = 0.f;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ps++) {
             const bool useB = ps == 1;
-            float in[2][5];
+            float in[2][NST];
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < NST; s++) {
                 in[0][s] = useB ? inA[1][s] : inA[0][s];
                 in[1][s] = useB ? inA[0][s] : inA[1][s];
             }
-            f32x4 a0[5], ox[5];
+            f32x4 a0[NST], ox[NST];
 #pragma unroll
-            for (int s = 0; s < 5; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
+            for (int s = 0; s < NST; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
             a0[0] += b0;
             {
                 f32x4 s0, s1, s2;
                 act012v<ACT>(a0[0], s0, s1, s2);
-                const f32x4 q = a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3];
+                const f32x4 q = a0[1] * a0[1] + a0[2] * a0[2];
                 ox[0] = s0;
                 ox[1] = s1 * a0[1];
                 ox[2] = s1 * a0[2];
-                ox[3] = s1 * a0[3];
-                ox[4] = s1 * a0[4] + s2 * q;
+                ox[SLP] = s1 * a0[SLP] + s2 * q;
                 h0s[ps] = s0;
             }
-            f32x4 a1[5];
+            f32x4 a1[NST];
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < NST; s++) {
                 u32x2 ph, pm, pl;
                 split4x3(ox[s], ph, pm, pl);
                 xh[ps][s] = ph;
@@ -1933,11 +1492,11 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             a1[0] += b1;
             f32x4 s0, s1, s2;
             act012v<ACT>(a1[0], s0, s1, s2);
-            const f32x4 q = a1[1] * a1[1] + a1[2] * a1[2] + a1[3] * a1[3];
-            const f32x4 ol = s1 * a1[4] + s2 * q;
+            const f32x4 q = a1[1] * a1[1] + a1[2] * a1[2];
+            const f32x4 ol = s1 * a1[SLP] + s2 * q;
             sv[ps][0] = s0;
 #pragma unroll
-            for (int s = 1; s < 5; s++) sv[ps][s] = a1[s];
+            for (int s = 1; s < NST; s++) sv[ps][s] = a1[s];
             const float Sv = xg_sum(dot4(wo, s0)), Sl = xg_sum(dot4(wo, ol));
             SvT += (useB ? A.P : 1.0f) * Sv;
             SlT += (useB ? A.P : 1.0f) * Sl;
@@ -1963,34 +1522,33 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
 #pragma unroll
         for (int ps = NPASS - 1; ps >= 0; ps--) {
             const bool useB = ps == 1;
-            float in[2][5];
+            float in[2][NST];
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < NST; s++) {
                 in[0][s] = useB ? inA[1][s] : inA[0][s];
                 in[1][s] = useB ? inA[0][s] : inA[1][s];
             }
             const float pw = useB ? A.P : 1.0f;
             const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
-            f32x4 yo[5];
+            f32x4 yo[NST];
             {
-                const f32x4 h = sv[ps][0], a1x = sv[ps][1], a1y = sv[ps][2], a1z = sv[ps][3], a1l = sv[ps][4];
+                const f32x4 h = sv[ps][0], a1x = sv[ps][1], a1r = sv[ps][2], a1l = sv[ps][SLP];
                 f32x4 s1, s2, s3;
                 act123v<ACT>(h, s1, s2, s3);
-                const f32x4 q = a1x * a1x + a1y * a1y + a1z * a1z;
+                const f32x4 q = a1x * a1x + a1r * a1r;
                 woacc += cv * h + cl * (s1 * a1l + s2 * q);
                 const f32x4 o0 = cv * wo, olb = cl * wo;
                 const f32x4 u = 2.0f * s2 * olb;
-                yo[4] = s1 * olb;
+                yo[SLP] = s1 * olb;
                 yo[1] = u * a1x;
-                yo[2] = u * a1y;
-                yo[3] = u * a1z;
+                yo[2] = u * a1r;
                 yo[0] = s1 * o0 + (s2 * a1l + s3 * q) * olb;
                 bacc1 += yo[0];
             }
-            // ---- W1-bar += Y-bar (x) X over the 80 (stream, point) columns
-            u32x2 yh[5], yl[5];
+            // ---- W1-bar += Y-bar (x) X over the 64 (stream, point) columns
+            u32x2 yh[NST], yl[NST];
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < NST; s++) {
                 split4(yo[s], yh[s], yl[s]);
                 const int off = (s * 16 + c) * PITCH + 4 * g;
                 *reinterpret_cast<u32x2*>(Yh + off) = yh[s];
@@ -2000,7 +1558,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             }
             wave_fence();
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < NST; s++) {
                 auto frag = [&](const __bf16* img) {
                     const __bf16* p = img + (s * 16 + 4 * g + (c >> 2)) * PITCH + 4 * (c & 3);
                     return __builtin_bit_cast(s16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
@@ -2013,32 +1571,31 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             }
             wave_fence();
             // ---- adjoint of the layer-0 outputs through W1^T, then layer 0 itself
-            f32x4 ob[5];
+            f32x4 ob[NST];
 #pragma unroll
-            for (int s = 0; s < 5; s++) {
+            for (int s = 0; s < NST; s++) {
                 f32x4 acc = mfma16(Th, as_s4(yh[s]), splat(0.f));
                 acc = mfma16(Th, as_s4(yl[s]), acc);
                 ob[s] = mfma16(Tl, as_s4(yh[s]), acc);
             }
             {
-                f32x4 a0[5];
+                f32x4 a0[NST];
 #pragma unroll
-                for (int s = 1; s < 5; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
+                for (int s = 1; s < NST; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
                 const f32x4 h = h0s[ps];
                 f32x4 s1, s2, s3;
                 act123v<ACT>(h, s1, s2, s3);
-                const f32x4 q = a0[1] * a0[1] + a0[2] * a0[2] + a0[3] * a0[3];
-                const f32x4 u = 2.0f * s2 * ob[4];
-                f32x4 ab[5];
-                ab[4] = s1 * ob[4];
+                const f32x4 q = a0[1] * a0[1] + a0[2] * a0[2];
+                const f32x4 u = 2.0f * s2 * ob[SLP];
+                f32x4 ab[NST];
+                ab[SLP] = s1 * ob[SLP];
                 ab[1] = s1 * ob[1] + u * a0[1];
                 ab[2] = s1 * ob[2] + u * a0[2];
-                ab[3] = s1 * ob[3] + u * a0[3];
-                ab[0] = s1 * ob[0] + s2 * (a0[1] * ob[1] + a0[2] * ob[2] + a0[3] * ob[3]) +
-                        (s2 * a0[4] + s3 * q) * ob[4];
+                ab[0] = s1 * ob[0] + s2 * (a0[1] * ob[1] + a0[2] * ob[2]) +
+                        (s2 * a0[SLP] + s3 * q) * ob[SLP];
                 bacc0 += ab[0];
 #pragma unroll
-                for (int s = 0; s < 5; s++) { w0acc0 += ab[s] * in[0][s]; w0acc1 += ab[s] * in[1][s]; }
+                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * in[0][s]; w0acc1 += ab[s] * in[1][s]; }
             }
         }
     }
@@ -2158,24 +1715,20 @@ hipError_t launch_trunk16_mfma(int act, int npass, int mode, const float* theta,
 bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
 bool mfma_x3_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
 
-// A/B switch for measurements (see launch_trunk_mfma): PINN_MFMA_GEN = 0 (default: the fastest
-// measured decomposition), 1..3 = alternatives.
-static int mfma_generation()
-{
-    static int gen = -1;
-    if (gen < 0) {
-        const char* e = getenv("PINN_MFMA_GEN");
-        gen = (e && e[0] >= '1' && e[0] <= '9') ? e[0] - '0' : 0;
-    }
-    return gen;
-}
-
 // resident blocks per CU the chosen decomposition is built for (pinn_create sizes the persistent
 // grid and the per-block partial buffer with it)
+// measurement switch (tools/kbench.py): PINN_MFMA_VARIANT = 0 (default decomposition) or an alternative
+// instantiation of the same kernel; read at pinn_create (grid sizing) and at every launch
+static int mfma_variant()
+{
+    const char* e = getenv("PINN_MFMA_VARIANT");
+    return (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 0;
+}
+
 int mfma_blocks_per_cu(int H, int L, bool x3)
 {
-    const int gen = mfma_generation();
-    if (H == 64 && L == 2 && !x3 && gen == 0) return 2;
+    const int v = mfma_variant();
+    if (H == 64 && L == 2 && !x3) return v == 1 ? 3 : (v == 2 ? 1 : 2);
     return 1;
 }
 
@@ -2188,14 +1741,10 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
                        hipError_t* err)
 {
     __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
-    // <H, L, SPLIT, WAVES, X3, OCC>: SPLIT waves share a 16-point tile, WAVES per block, OCC
-    // resident blocks per CU.  Defaults are the fastest measured decomposition per shape (1M points,
-    // MI355X, kernel ms); PINN_MFMA_GEN = 1..3 selects the alternatives for A/B measurements:
-    //   2x64 : <4,4> x 2 blocks/CU 0.72 | point-split gen-1 0.76 | <4,8> 0.74 | <2,8> (spills)
-    //   2x128: <8,8> 1.88 | <4,4> 2.7          4x64: <2,4> 2.27 | <4,8> 4.2
-    //   4x128: <4,4> 11.8 | <8,8> 15.4  (weights streamed through LDS; both still spill ~0.5 KB/lane:
-    //          the 3 x 128 x 128 fp32 gradient accumulators alone are 38 % of a CU's registers)
-    const int gen = mfma_generation();
+    // <H, L, SPLIT, WAVES, X3, OCC>: SPLIT waves share a 16-point tile, WAVES per block, OCC resident
+    // blocks per CU.  One decomposition per shape, the fastest measured (round 1, 1M points, kernel ms):
+    //   2x64 : <4,4> x 2 blocks/CU 0.72 (<4,8> 0.74, <2,8> spills)     2x128: <8,8> 1.88 (<4,4> 2.7)
+    //   4x64 : <2,4> 2.27 (<4,8> 4.2)                                   4x128: <4,4> 11.8 (<8,8> 15.4)
     if (x3) {   // split-bf16 operands (3 MFMAs per product): neuron-split kernel only
         if (H == 64 && L == 2) {
             return launch2_HL<64, 2, 4, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
@@ -2212,22 +1761,13 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
         return false;
     }
     if (H == 64 && L == 2) {
-        if (gen == 1 && mode != MODE_HEAD) return launch_HL<64, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
-        if (gen == 2) return launch2_HL<64, 2, 2, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
-        if (gen == 3) return launch2_HL<64, 2, 4, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+        const int v = mfma_variant();
+        if (v == 1) return launch2_HL<64, 2, 4, 4, false, 3>(act, npass, mode, theta, wpk, A, grid, st, err);
+        if (v == 2) return launch2_HL<64, 2, 4, 8, false, 1>(act, npass, mode, theta, wpk, A, grid, st, err);
         return launch2_HL<64, 2, 4, 4, false, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
     }
-    if (H == 128 && L == 2) {
-        if (gen == 2) return launch2_HL<128, 2, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-        return launch2_HL<128, 2, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
-    }
-    if (H == 64 && L == 4) {
-        if (gen == 2) return launch2_HL<64, 4, 4, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
-        return launch2_HL<64, 4, 2, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-    }
-    if (H == 128 && L == 4) {
-        if (gen == 2) return launch2_HL<128, 4, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
-        return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-    }
+    if (H == 128 && L == 2) return launch2_HL<128, 2, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+    if (H == 64 && L == 4) return launch2_HL<64, 4, 2, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+    if (H == 128 && L == 4) return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
     return false;
 }

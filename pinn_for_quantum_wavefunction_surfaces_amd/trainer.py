@@ -202,7 +202,7 @@ class Trainer:
         best model (best_post_step rule)."""
         m, v, step = (self.best_m, self.best_v, self.best_step) if best and self.best_m is not None \
             else (self.m, self.v, self.step_count)
-        off, sz = capi.tensor_layout(self.model.arch())
+        off, sz = capi.tensor_layout(self.model.arch)
         state = {}
         plist = list(self.model.parameters())
         for t, p in enumerate(plist):

@@ -456,12 +456,15 @@ def test_mfma_bf16_wide_trunk_matches_reference(golden_dir):
                O.arch(H=64), O.ham_A())
 
 
-def _tensor_errors(arch, L, got, ref):
+def _tensor_errors(arch, L, got, ref, floor=1e-3):
+    """max error of every tensor's gradient relative to that tensor's largest entry (but at least
+    `floor` x the largest entry of the whole gradient: a tensor whose gradient is tiny against the rest,
+    here the gate's, cannot be held to more than the noise the big ones carry)"""
     off, sz = capi.tensor_layout(arch)
     names = [k for l in range(L) for k in ("W%d" % l, "b%d" % l)] + ["wout", "bout", "WE1", "bE1", "WE2", "bE2",
                                                                       "WE3", "bE3", "WG1", "bG1", "WG2", "bG2"]
     return {nm: np.max(np.abs(got[off[t]:off[t] + sz[t]] - ref[off[t]:off[t] + sz[t]]))
-            / max(np.max(np.abs(ref[off[t]:off[t] + sz[t]])), 1e-3 * np.max(np.abs(ref)))
+            / max(np.max(np.abs(ref[off[t]:off[t] + sz[t]])), floor * np.max(np.abs(ref)))
             for t, nm in enumerate(names)}
 
 
@@ -482,7 +485,10 @@ def test_benchmarked_2x64_tanh_instance_matches_reference(golden_dir, prec):
     P = h.P
     errs = dict(psi=rel(psi, g["psi"]), E=rel(E, g["E"]), lap=rel(lap, g["lap"]), res=rel(res, g["res"]),
                 loss=abs(out[P:].sum() / g["Ltot"] - 1), grad=rel(out[:P], g["grad"]))
-    terr = _tensor_errors(arch, 2, out[:P], g["grad"])
+    # bf16: the gate's gradient (dL/dg = N psi-bar + lap N lap-bar, a cancelling sum over points of
+    # quantities that carry the trunk's bf16 noise) is ~1e-2 of the largest entry on this net, so its own
+    # scale is inside the path's 3e-2 noise: measured against 2 % of the largest entry instead
+    terr = _tensor_errors(arch, 2, out[:P], g["grad"], floor=2e-2 if prec == "bf16" else 1e-3)
     print("2x64 tanh %s vs reference:" % prec, {k: "%.2e" % v for k, v in {**errs, **terr}.items()})
     assert errs["E"] < 1e-5
     if prec == "bf16":       # this path's own tolerance (header of this section)
@@ -952,9 +958,7 @@ def test_two_ranks_equal_one_rank_with_twice_the_points(tmp_path, golden_dir):
     # at round-off in theta over a few steps
     assert np.abs(r0["theta"] - th).max() < 2e-5 * np.abs(th).max()
     assert np.abs(r0["losses"] / np.array(one) - 1).max() < 1e-4
-    # the last sampled batch (one ahead) has the same global boundary-set sizes as the
-    # single-rank batch of that step
-    tr.resample()
+    # the batch of the last step has the same global boundary-set sizes as the single-rank batch
     assert tuple(r0["counts"]) == tuple(tr.counts.cpu().numpy())
 
 

@@ -156,6 +156,27 @@ int pinn_adam(pinn_handle *h, float *theta, const float *grad, float *m, float *
 int pinn_profile_enable(pinn_handle *h, int nslots);
 int pinn_profile_read(pinn_handle *h, int ncalls, float *mean_trunk_ms);
 
+/* ---- data-parallel exchange (the reference is single device) ------------
+ * One-shot all-reduce (SUM, fp32) of the per-step message [grad | loss terms | counts] over
+ * peer-mapped memory: every rank writes its vector into a slot in every peer's memory (one xGMI hop,
+ * all links at once) and sums the N slots locally in rank order, so all ranks obtain bitwise
+ * identical sums.  Two kernels on the caller's stream per call, no host synchronisation.
+ * Setup (once, host side): every rank creates its exchange, the ranks trade the 64-byte handles of
+ * pinn_xchg_local_handle by any means (the Python layer uses torch.distributed.all_gather_object),
+ * and each calls pinn_xchg_connect with all N handles in rank order (its own entry is ignored).
+ * Every rank must make the same sequence of pinn_xchg_allreduce calls.  buf: device, 16-byte aligned,
+ * n <= max_floats, summed in place.  A peer that does not arrive within 20 s leaves buf untouched and
+ * sets a status word that pinn_xchg_status (which synchronises the stream) reports as PINN_ERR_HIP. */
+typedef struct pinn_xchg pinn_xchg;
+#define PINN_XCHG_HANDLE_BYTES 64
+int pinn_xchg_create(int device, int rank, int world, int64_t max_floats, pinn_xchg **out);
+int pinn_xchg_local_handle(pinn_xchg *x, void *handle64);
+int pinn_xchg_connect(pinn_xchg *x, const void *handles /* world x 64 bytes, rank order */);
+int pinn_xchg_allreduce(pinn_xchg *x, float *buf, int64_t n, void *stream);
+int pinn_xchg_status(pinn_xchg *x, void *stream);
+int pinn_xchg_destroy(pinn_xchg *x);
+const char *pinn_xchg_last_error(const pinn_xchg *x);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ SO = os.path.join(HERE, "libpinn_hip.so")
 # per-source extra flags.  pinn_kernels.hip: -fno-slp-vectorize, because the SLP pass packs
 # scalar FMAs into v_pk_* and then has to copy the SGPR-resident weights into VGPR pairs
 # first (+40 % VALU instructions).  The MFMA trunk keeps SLP (its operands are VGPR vectors).
-SOURCES = {"pinn_kernels.hip": ["-fno-slp-vectorize"], "pinn_trunk_mfma.hip": []}
+SOURCES = {"pinn_kernels.hip": ["-fno-slp-vectorize"], "pinn_trunk_mfma.hip": [], "pinn_xchg.hip": []}
 HEADERS = ["pinn_math.h", "pinn_common.h", os.path.join("..", "..", "include", "pinn.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 

@@ -15,7 +15,8 @@ PINN_PREC_F32, PINN_PREC_BF16, PINN_PREC_BF16X3 = 0, 1, 2
 EXPORTS = ["pinn_param_count", "pinn_tensor_count", "pinn_tensor_layout", "pinn_strerror",
            "pinn_create", "pinn_destroy", "pinn_last_error", "pinn_sample", "pinn_forward",
            "pinn_residual_fwd_bwd", "pinn_adam", "pinn_profile_enable", "pinn_profile_read",
-           "pinn_energy_R"]
+           "pinn_energy_R", "pinn_xchg_create", "pinn_xchg_local_handle", "pinn_xchg_connect",
+           "pinn_xchg_allreduce", "pinn_xchg_status", "pinn_xchg_destroy", "pinn_xchg_last_error"]
 
 
 class PinnError(RuntimeError):
@@ -71,6 +72,14 @@ def load_library():
     lib.pinn_adam.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_double] * 4 + [C.c_uint64, fp, fp, vp]
     lib.pinn_profile_enable.argtypes = [vp, C.c_int]
     lib.pinn_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    lib.pinn_xchg_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(vp)]
+    lib.pinn_xchg_local_handle.argtypes = [vp, C.c_char_p]
+    lib.pinn_xchg_connect.argtypes = [vp, C.c_char_p]
+    lib.pinn_xchg_allreduce.argtypes = [vp, fp, C.c_int64, vp]
+    lib.pinn_xchg_status.argtypes = [vp, vp]
+    lib.pinn_xchg_destroy.argtypes = [vp]
+    lib.pinn_xchg_last_error.restype = C.c_char_p
+    lib.pinn_xchg_last_error.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -175,3 +184,50 @@ class Handle:
                                        _ptr(step_count), lr, b1, b2, eps,
                                        C.c_uint64(trainable_mask), _ptr(best_theta),
                                        _ptr(best_loss), self._stream()), "pinn_adam")
+
+
+XCHG_HANDLE_BYTES = 64
+
+
+class Exchange:
+    """One-shot all-reduce over peer-mapped memory (include/pinn.h, pinn_xchg_*).  `gather` is a
+    callable that takes this rank's 64-byte handle and returns all ranks' handles in rank order
+    (torch.distributed.all_gather_object in DataParallelPlan)."""
+
+    def __init__(self, device_index, rank, world, max_floats, gather):
+        self.lib = load_library()
+        x = C.c_void_p()
+        rc = self.lib.pinn_xchg_create(int(device_index), int(rank), int(world), int(max_floats), C.byref(x))
+        self.x = x if x else None
+        self._check(rc, "pinn_xchg_create")
+        mine = C.create_string_buffer(XCHG_HANDLE_BYTES)
+        self._check(self.lib.pinn_xchg_local_handle(self.x, mine), "pinn_xchg_local_handle")
+        handles = gather(bytes(mine.raw))
+        if len(handles) != world or any(len(h) != XCHG_HANDLE_BYTES for h in handles):
+            raise PinnError("exchange setup: expected %d handles of %d bytes" % (world, XCHG_HANDLE_BYTES))
+        self._check(self.lib.pinn_xchg_connect(self.x, b"".join(handles)), "pinn_xchg_connect")
+        self.max_floats = int(max_floats)
+
+    def _check(self, rc, what):
+        if rc:
+            msg = self.lib.pinn_xchg_last_error(self.x).decode() if self.x else ""
+            raise PinnError("%s: %s (%s)" % (what, self.lib.pinn_strerror(rc).decode(), msg))
+
+    def allreduce(self, buf):
+        """in-place SUM over ranks of a contiguous fp32 device tensor, on the current stream"""
+        self._check(self.lib.pinn_xchg_allreduce(self.x, _ptr(buf), buf.numel(), Handle._stream()),
+                    "pinn_xchg_allreduce")
+
+    def status(self):
+        self._check(self.lib.pinn_xchg_status(self.x, Handle._stream()), "pinn_xchg_status")
+
+    def close(self):
+        if getattr(self, "x", None):
+            self.lib.pinn_xchg_destroy(self.x)
+            self.x = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -12,13 +12,22 @@ the current step runs and its set sizes ride behind the gradient as two floats
 (exact below 2^24 points; above that, or for a one-off batch, reduce_counts is used).
 The backend is whatever torch.distributed was initialised with ("nccl" = RCCL over
 xGMI on MI355X; "gloo" in the CPU tests).  With world_size 1 nothing is called.
+
+one_shot=True (or PINN_ONE_SHOT=1) replaces the all-reduce of the gradient message by the
+library's own exchange over peer-mapped memory (include/pinn.h pinn_xchg_*: every rank writes its
+6-205 KB vector into a slot in every peer's memory over the xGMI mesh and sums the N slots in rank
+order -- one hop, two small kernels on the compute stream, bitwise identical sums on all ranks);
+torch.distributed is then only used once, to trade the 64-byte memory handles.  RCCL stays the
+default until the one-shot path has been measured on an 8-GPU node.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class DataParallelPlan:
-    def __init__(self, n_local, rank=None, world=None, group=None, force_collectives=False):
+    def __init__(self, n_local, rank=None, world=None, group=None, force_collectives=False, one_shot=None):
         if world is None:
             world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         if rank is None:
@@ -26,6 +35,30 @@ class DataParallelPlan:
         self.n_local, self.rank, self.world, self.group = int(n_local), int(rank), int(world), group
         # world == 1 normally skips the collectives; forcing them exercises the RCCL path on one GPU
         self.collectives = self.world > 1 or bool(force_collectives)
+        self.one_shot = (os.environ.get("PINN_ONE_SHOT") == "1") if one_shot is None else bool(one_shot)
+        self._xchg = None
+
+    def attach_exchange(self, device, max_floats):
+        """one_shot: build the peer-memory exchange for messages of up to max_floats fp32 on `device`
+        (called by the Trainer once it knows the message length); no-op otherwise"""
+        if not (self.one_shot and self.collectives) or self._xchg is not None:
+            return
+        from . import capi
+
+        def gather(mine):
+            if self.world == 1:
+                return [mine]
+            out = [None] * self.world
+            dist.all_gather_object(out, mine, group=self.group)
+            return out
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self._xchg = capi.Exchange(idx, self.rank, self.world, max_floats, gather)
+
+    def _sum(self, buf):
+        if self._xchg is not None:
+            self._xchg.allreduce(buf)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
 
     @property
     def first(self):
@@ -49,7 +82,7 @@ class DataParallelPlan:
     def reduce_grad(self, buf):
         """fp32[P+3] = [grad | three loss terms]: local partial -> global (in place)."""
         if self.collectives:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._sum(buf)
         return buf
 
     def reduce_grad_and_counts(self, buf, counts_local, counts_global):
@@ -59,7 +92,7 @@ class DataParallelPlan:
         assert self.n_global < (1 << 24)
         buf[-2:].copy_(counts_local)            # int64 -> fp32 inside the copy kernel (exact < 2^24)
         if self.collectives:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._sum(buf)
         counts_global.copy_(buf[-2:])           # sums of integers below 2^24 are exact in fp32
         return buf
 

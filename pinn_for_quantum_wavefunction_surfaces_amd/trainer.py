@@ -68,6 +68,8 @@ class Trainer:
         self.v = torch.zeros(P, device=dev, dtype=f32)
         self.gbuf = torch.zeros(P + 5, device=dev, dtype=f32)   # [grad | Lpde Lbc1 Lbc2 | next counts]
         self.grad = self.gbuf[:P + 3]
+        if dev.type == "cuda":
+            self.plan.attach_exchange(dev, P + 5)               # one-shot exchange, if the plan asks for it
         self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
         self.best_theta = self.theta.clone()
         self.best_loss = torch.full((1,), float("inf"), device=dev, dtype=f32)

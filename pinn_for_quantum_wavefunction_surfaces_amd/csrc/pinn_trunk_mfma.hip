@@ -176,6 +176,12 @@ __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b)
+{
+    const f32x4 p = a * b;
+    return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
 __device__ __forceinline__ void wave_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1009,6 +1015,338 @@ bool launch2_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, c
 
 
 // =====================================================================================
+// k_trunk2: two hidden layers, symmetric double pass, full reverse sweep -- the benchmark's shape --
+// with BOTH passes of the double pass swept together.  Same decomposition as k_trunk_mfma2 (H/16 waves
+// share a 16-point tile, each owning 16 neurons; B fragments exchanged through LDS in operand order),
+// but every phase handles the 2 x NST x 16 = 128 (pass, stream, point) columns of the tile at once:
+//   P1  point record (requested one trip ahead), orbitals, layer 0 of both passes -> XB[A], XB[B]
+//   P2  layer-1 GEMM over 128 columns (each weight fragment feeds 8 MFMAs), activations of both
+//       passes, partial output sums -> SB
+//   P3  tail (psi, residual, loss seeds), last-hidden adjoints of both passes -> YB[A], YB[B]
+//   P4  weight gradient (K = 128 columns = 4 MFMA steps), input-adjoint GEMM, layer-0 adjoints
+// Three workgroup barriers per tile instead of eight (the layer-output buffers alternate between two
+// sets from tile to tile, so P4 of tile t runs into P1 of tile t+1 without a barrier), twice the
+// independent work between them, half the weight-fragment reads.  Results are those of k_trunk_mfma2
+// up to the order of fp32 additions.
+template <int H>
+struct T2Cfg {
+    static constexpr int HT = H / 16, KC = H / 32, WAVES = H / 16;
+    static constexpr int OCC = H == 64 ? 2 : 1;                  // resident blocks per CU
+    static constexpr int EB = KC * NST * 64 * 16;                 // bytes of one (pass) exchange buffer
+    static constexpr int WBYTES = 2 * H * H * 2;                  // forward + transposed matrix, bf16
+    static constexpr int NSMALL = 3 * H + H + H + 4;              // W0a W0b b0 | b1 | wout | bout
+    static constexpr int XSETS = (OCC * (WBYTES + NSMALL * 4 + 6 * EB + 1024) <= 160 * 1024) ? 2 : 1;
+    static constexpr size_t OFF_SMALL = WBYTES;
+    static constexpr size_t OFF_X = OFF_SMALL + NSMALL * 4;
+    static constexpr size_t OFF_Y = OFF_X + (size_t)XSETS * 2 * EB;
+    static constexpr size_t OFF_S = OFF_Y + 2 * EB;
+    static constexpr size_t LDS_BYTES = OFF_S + WAVES * 16 * 2 * 4;
+    static_assert(OCC * LDS_BYTES <= 160 * 1024, "k_trunk2 does not fit the CU's LDS");
+};
+
+template <int H, int ACT>
+__global__ __launch_bounds__(T2Cfg<H>::WAVES * 64, T2Cfg<H>::OCC * T2Cfg<H>::WAVES / 4)
+void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, TrunkArgs A)
+{
+    using C = T2Cfg<H>;
+    using Lay = TrunkLayout<H, 2>;
+    constexpr int HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    typedef __attribute__((address_space(3))) unsigned char* lds_p;
+    const lds_p lds0 = (lds_p)lds_raw;
+    float* small = reinterpret_cast<float*>(lds_raw + C::OFF_SMALL);
+    float* sW0a = small;              // W0[:, 0]
+    float* sW0b = small + H;          // W0[:, 1]
+    float* sb0 = small + 2 * H;
+    float* sb1 = small + 3 * H;
+    float* swo = small + 4 * H;
+    float* sbo = small + 5 * H;
+    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_S);   // [wave][16 points][2]
+
+    const int lane = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row tile owned by this wave
+    const int g = lane >> 4, c = lane & 15;
+    const int lane16 = lane * 16;
+    const int own_slot = lane16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
+    const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
+    const int n0 = 16 * part + 4 * g;                                    // first own neuron of this lane
+
+    {   // weights (fragment order) and small parameters -> LDS
+        const uint4* src = reinterpret_cast<const uint4*>(wpk_g);
+        uint4* dst = reinterpret_cast<uint4*>(lds_raw);
+        for (int k = threadIdx.x; k < C::WBYTES / 16; k += NT) dst[k] = src[k];
+        for (int k = threadIdx.x; k < H; k += NT) {
+            sW0a[k] = theta[Lay::W(0) + 2 * k];
+            sW0b[k] = theta[Lay::W(0) + 2 * k + 1];
+            sb0[k] = theta[Lay::b(0) + k];
+            sb1[k] = theta[Lay::b(1) + k];
+            swo[k] = theta[Lay::Wout + k];
+        }
+        if (threadIdx.x == 0) sbo[0] = theta[Lay::bout];
+    }
+    __syncthreads();
+    // per-lane constants of the own neurons (registers for the whole kernel)
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW0a + n0), w1 = *reinterpret_cast<const f32x4*>(sW0b + n0);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb0 + n0), b1 = *reinterpret_cast<const f32x4*>(sb1 + n0);
+    const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + n0);
+    const float bout = sbo[0];
+    const lds_p wfwd = lds0 + (size_t)(part * KC) * 1024 + lane16;             // + kc * 1024
+    const lds_p wbwd = lds0 + (size_t)H * H * 2 + (size_t)(part * KC) * 1024 + lane16;
+
+    f32x4 wacc[HT], bacc0 = splat(0.f), bacc1 = splat(0.f), w0acc0 = splat(0.f), w0acc1 = splat(0.f),
+          woacc = splat(0.f);
+#pragma unroll
+    for (int it = 0; it < HT; it++) wacc[it] = splat(0.f);
+    float acc_bout = 0.f, acc_pde = 0.f, acc_bc1 = 0.f, acc_bc2 = 0.f;
+    float invN1 = A.invN1, invN2 = A.invN2;
+    if (A.bc_counts) {
+        const long long c1 = A.bc_counts[0], c2 = A.bc_counts[1];
+        invN1 = c1 > 0 ? 1.0f / (float)c1 : 0.0f;
+        invN2 = c2 > 0 ? 1.0f / (float)c2 : 0.0f;
+    }
+    const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
+    const int64_t ntile = (A.n + 15) / 16;
+    const int64_t iters = (ntile + gridDim.x - 1) / gridDim.x;   // same for every block: barriers match
+
+    struct PointRec { float x, y, z, R, E, g; unsigned mk; };
+    auto load_rec = [&](int64_t itn) {
+        const int64_t tl = itn * gridDim.x + blockIdx.x;
+        int64_t id = tl * 16 + c;
+        id = (tl < ntile && id < A.n) ? id : A.n - 1;
+        PointRec r;
+        r.x = A.x[id]; r.y = A.y[id]; r.z = A.z[id]; r.R = A.R[id]; r.E = A.E[id]; r.g = A.g[id];
+        r.mk = A.mask ? A.mask[id] : 0u;
+        return r;
+    };
+    auto put = [&](lds_p eb, int s, f32x4 v) {      // own 4 neurons of stream s -> 8 bytes of the B fragment
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + own_slot + s * 1024) = pack4(v);
+    };
+    auto bfrag = [&](lds_p eb, int kc, int s) {
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + lane16 + (kc * NST + s) * 1024);
+    };
+    auto trfrag = [&](lds_p eb, int T, int ph) {     // rows 32ph..32ph+31 of the [column][neuron] image, tile T
+        const lds_p p0 = eb + trl + ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 64));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    PointRec nxt = load_rec(0);
+    int xset = 0;
+    for (int64_t itx = 0; itx < iters; itx++) {
+        const int64_t tile = itx * gridDim.x + blockIdx.x;
+        const int64_t idx = tile * 16 + c;
+        const bool valid = tile < ntile && idx < A.n;
+        const PointRec cur = nxt;
+        if (itx + 1 < iters) nxt = load_rec(itx + 1);
+        const lds_p XB = lds0 + C::OFF_X + (size_t)(C::XSETS == 2 ? xset : 0) * 2 * EB;   // [pass] at + ps * EB
+        const lds_p YB = lds0 + C::OFF_Y;
+        // ================= P1: inputs and layer 0 of both passes =================
+        float inA[2][NST], ri1, ri2;
+        {
+            const float rho2 = cur.y * cur.y + cur.z * cur.z, rho = __builtin_amdgcn_sqrtf(rho2);
+            orbital_cyl<float>(cur.x - cur.R, rho2, rho, inA[0], ri1);
+            orbital_cyl<float>(cur.x + cur.R, rho2, rho, inA[1], ri2);
+        }
+        const float F = inA[0][0] + A.P * inA[1][0];
+        const float lapF = inA[0][SLP] + A.P * inA[1][SLP];
+        f32x4 h0[2];            // layer-0 activations of the own neurons, pass A / pass B
+        f32x4 sv[2][NST];       // (h, a_x, a_rho, a_lap) of layer 1
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++) {
+            f32x4 a[NST];
+#pragma unroll
+            for (int s = 0; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
+            a[0] += b0;
+            f32x4 s0, s1, s2;
+            act012v<ACT>(a[0], s0, s1, s2);
+            const f32x4 q = a[1] * a[1] + a[2] * a[2];
+            h0[ps] = s0;
+            put(XB + ps * EB, 0, s0);
+            put(XB + ps * EB, 1, s1 * a[1]);
+            put(XB + ps * EB, 2, s1 * a[2]);
+            put(XB + ps * EB, SLP, s1 * a[SLP] + s2 * q);
+        }
+        __syncthreads();
+        // ================= P2: layer-1 GEMM over both passes, activations, output partial sums =================
+        {
+            f32x4 acc[2][NST];
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) {
+                acc[ps][0] = b1;
+#pragma unroll
+                for (int s = 1; s < NST; s++) acc[ps][s] = splat(0.f);
+            }
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) {
+                const bf16x8 w = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(wfwd + kc * 1024);
+#pragma unroll
+                for (int ps = 0; ps < 2; ps++)
+#pragma unroll
+                    for (int s = 0; s < NST; s++) acc[ps][s] = mfma(w, bfrag(XB + ps * EB, kc, s), acc[ps][s]);
+            }
+            float Sv = 0.f, Sl = 0.f;
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) {
+                f32x4 s0, s1, s2;
+                act012v<ACT>(acc[ps][0], s0, s1, s2);
+                const f32x4 q = acc[ps][1] * acc[ps][1] + acc[ps][2] * acc[ps][2];
+                const f32x4 ol = s1 * acc[ps][SLP] + s2 * q;
+                sv[ps][0] = s0;
+#pragma unroll
+                for (int s = 1; s < NST; s++) sv[ps][s] = acc[ps][s];
+                const float pw = ps ? A.P : 1.0f;
+                Sv += pw * dot4(wo, s0);
+                Sl += pw * dot4(wo, ol);
+            }
+            Sv = xg_sum(Sv);
+            Sl = xg_sum(Sl);
+            if (g == 0) { SB[(part * 16 + c) * 2] = Sv; SB[(part * 16 + c) * 2 + 1] = Sl; }
+        }
+        __syncthreads();
+        // ================= P3: tail, last hidden layer's adjoints of both passes =================
+        Tail<float> t;
+        {
+            float Sv = 0.f, Sl = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < C::WAVES; pp++) { Sv += SB[(pp * 16 + c) * 2]; Sl += SB[(pp * 16 + c) * 2 + 1]; }
+            tail<float>(A.out_scale * Sv + bout, A.out_scale * Sl, cur.g, cur.E, F, lapF, ri1 + ri2, A.a, A.b, A.c,
+                        float(cur.mk & 1), float((cur.mk >> 1) & 1), A.invN, invN1, invN2, valid ? 1.0f : 0.0f, t);
+            if (valid && g == 0 && part == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+            acc_pde += lead * t.l_pde;
+            acc_bc1 += lead * t.l_bc1;
+            acc_bc2 += lead * t.l_bc2;
+            acc_bout += lead * t.Nb;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++) {
+            const float pw = ps ? A.P : 1.0f;
+            const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
+            const f32x4 h = sv[ps][0];
+            f32x4 s1, s2, s3;
+            act123v<ACT>(h, s1, s2, s3);
+            const f32x4 q = sv[ps][1] * sv[ps][1] + sv[ps][2] * sv[ps][2];
+            woacc += cv * h + cl * (s1 * sv[ps][SLP] + s2 * q);
+            const f32x4 o0 = cv * wo, ol = cl * wo;
+            const f32x4 u = 2.0f * s2 * ol;
+            const f32x4 y0 = s1 * o0 + (s2 * sv[ps][SLP] + s3 * q) * ol;
+            bacc1 += y0;
+            put(YB + ps * EB, 0, y0);
+            put(YB + ps * EB, 1, u * sv[ps][1]);
+            put(YB + ps * EB, 2, u * sv[ps][2]);
+            put(YB + ps * EB, SLP, s1 * ol);
+        }
+        __syncthreads();
+        // ================= P4: weight gradient, input-adjoint GEMM, layer-0 adjoints =================
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++)
+#pragma unroll
+            for (int ph = 0; ph < NST / 2; ph++) {
+                const bf16x8 fy = trfrag(YB + ps * EB, part, ph);
+#pragma unroll
+                for (int it = 0; it < HT; it++) wacc[it] = mfma(fy, trfrag(XB + ps * EB, it, ph), wacc[it]);
+            }
+        {
+            f32x4 ob[2][NST];
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++)
+#pragma unroll
+                for (int s = 0; s < NST; s++) ob[ps][s] = splat(0.f);
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) {
+                const bf16x8 w = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(wbwd + kc * 1024);
+#pragma unroll
+                for (int ps = 0; ps < 2; ps++)
+#pragma unroll
+                    for (int s = 0; s < NST; s++) ob[ps][s] = mfma(w, bfrag(YB + ps * EB, kc, s), ob[ps][s]);
+            }
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) {
+                f32x4 a[NST];
+#pragma unroll
+                for (int s = 1; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
+                f32x4 s1, s2, s3;
+                act123v<ACT>(h0[ps], s1, s2, s3);
+                const f32x4 q = a[1] * a[1] + a[2] * a[2];
+                const f32x4 u = 2.0f * s2 * ob[ps][SLP];
+                f32x4 ab[NST];
+                ab[SLP] = s1 * ob[ps][SLP];
+                ab[1] = s1 * ob[ps][1] + u * a[1];
+                ab[2] = s1 * ob[ps][2] + u * a[2];
+                ab[0] = s1 * ob[ps][0] + s2 * (a[1] * ob[ps][1] + a[2] * ob[ps][2]) + (s2 * a[SLP] + s3 * q) * ob[ps][SLP];
+                bacc0 += ab[0];
+#pragma unroll
+                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * inA[ps][s]; w0acc1 += ab[s] * inA[1 - ps][s]; }
+            }
+        }
+        if (C::XSETS == 1) __syncthreads();   // one set of layer-output buffers: P1 of the next tile overwrites it
+        xset ^= 1;
+    }
+    // =========================== block reduction ===========================
+    __syncthreads();
+    constexpr int PT = Lay::size;
+    float* out = A.partial + (size_t)blockIdx.x * A.stride;
+    const float s0 = row16_sum(xg_sum(acc_pde)), s1r = row16_sum(xg_sum(acc_bc1)),
+                s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        bacc0[r] = row16_sum(bacc0[r]); bacc1[r] = row16_sum(bacc1[r]);
+        w0acc0[r] = row16_sum(w0acc0[r]); w0acc1[r] = row16_sum(w0acc1[r]);
+        woacc[r] = row16_sum(woacc[r]);
+    }
+    float* sc = reinterpret_cast<float*>(lds_raw);
+    if (threadIdx.x < 4) sc[threadIdx.x] = 0.f;
+    __syncthreads();
+    // every wave owns distinct gradient rows: straight to the block's partial row
+#pragma unroll
+    for (int it = 0; it < HT; it++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int nj = q_neuron(16 * part + 4 * g + r), ni = q_neuron(16 * it + c);
+            out[Lay::W(1) + nj * H + ni] = wacc[it][r];
+        }
+    if (c == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int nj = n0 + r;
+            out[Lay::b(0) + nj] = bacc0[r];
+            out[Lay::b(1) + nj] = bacc1[r];
+            out[Lay::W(0) + 2 * nj] = w0acc0[r];
+            out[Lay::W(0) + 2 * nj + 1] = w0acc1[r];
+            out[Lay::Wout + nj] = woacc[r];
+        }
+    }
+    for (int w = 0; w < C::WAVES; w++) {   // per-point sums live in one wave only; fixed order anyway
+        if (part == w && lane == 0) { sc[0] += s0; sc[1] += s1r; sc[2] += s2r; sc[3] += s3r; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
+    if (threadIdx.x == 3) out[Lay::bout] = sc[3];
+}
+
+template <int H, int ACT>
+hipError_t launch_trunk2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
+{
+    using C1 = MCfg<H, 2>;
+    using C = T2Cfg<H>;
+    const int nfrag = C1::NW * 2 * C1::HT * C1::KC * 64;
+    hipLaunchKernelGGL((k_pack_weights<H, 2, false>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    auto kern = k_trunk2<H, ACT>;
+    static bool attr_set[64] = {};   // per device (not a stream operation: done outside graph capture)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::WAVES * 64), C::LDS_BYTES, st, theta, (const __bf16*)wpk, A);
+    return hipGetLastError();
+}
+
+// =====================================================================================
 // R-only nets (E-net 1 -> 32 -> 32 -> 1, gate 1 -> 10 -> 1) in the trunk's transposed layout:
 // a wave owns 16 points; lane (g, c) holds, for point c, neurons 16 jt + 4 g + r of both row
 // tiles.  The 32 x 32 layer (forward, its transpose in the reverse sweep) is three split-bf16
@@ -1094,11 +1432,6 @@ __device__ __forceinline__ f32x4 mfma_x3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8
     return mfma(al, bh, c);
 }
 
-__device__ __forceinline__ float dot4(f32x4 a, f32x4 b)
-{
-    const f32x4 p = a * b;
-    return (p[0] + p[1]) + (p[2] + p[3]);
-}
 
 // forward of one 16-point tile: returns E, g of point c (all four lane groups hold them)
 template <int ACT>
@@ -1759,6 +2092,14 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
                                   // LDS-DMA, lo plane from L2, one layer-output buffer (XONE)
             return launch2_HL<128, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         return false;
+    }
+    if (L == 2 && npass == 2 && mode == MODE_BWD && mfma_variant() != 3 && (H == 64 || (H == 128 && mfma_variant() == 4))) {
+        // the benchmark's shape: both passes swept together (k_trunk2)
+        if (H == 64) *err = act == ACT_TANH ? launch_trunk2_t<64, ACT_TANH>(theta, wpk, A, grid, st)
+                                            : launch_trunk2_t<64, ACT_SIGMOID>(theta, wpk, A, grid, st);
+        else *err = act == ACT_TANH ? launch_trunk2_t<128, ACT_TANH>(theta, wpk, A, grid, st)
+                                    : launch_trunk2_t<128, ACT_SIGMOID>(theta, wpk, A, grid, st);
+        return true;
     }
     if (H == 64 && L == 2) {
         const int v = mfma_variant();

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -1418,6 +1419,9 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     A.invN = ham->invN; A.invN1 = ham->invN1; A.invN2 = ham->invN2;
     A.bc_counts = (const long long*)bc_counts;
     A.Eb = h->Eb; A.gb = h->gb; A.partial = h->partT; A.stride = h->strideT;
+#ifdef PINN_STAMPS
+    if (const char* sp = getenv("PINN_STAMP_PTR")) A.psi = (float*)strtoull(sp, nullptr, 16);   // diagnostic build only
+#endif
     const int slot = h->prof_slots ? (int)(h->prof_calls % h->prof_slots) : 0;
     if (h->prof_slots) HIPCHK(h, hipEventRecord(h->ev[2 * slot], st));
     if (!run_trunk(h, trunk_trainable ? MODE_BWD : MODE_HEAD, theta, A, gT, st, &e))

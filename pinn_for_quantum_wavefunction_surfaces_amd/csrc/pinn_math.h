@@ -49,6 +49,14 @@ PINN_HD float p_exp(float x) { return std::exp(x); }
 PINN_HD float p_rcp(float x) { return 1.0f / x; }
 PINN_HD float p_rsqrt(float x) { return 1.0f / std::sqrt(x); }
 #endif
+// exp(k x) for a compile-time constant k: the constant is folded into the exponent scaling, one
+// multiply in front of v_exp_f32 instead of two (tanh's exp(-2a))
+#if defined(__HIP_DEVICE_COMPILE__)
+PINN_HD float p_expk(float x, float k) { return __builtin_amdgcn_exp2f(x * (k * 1.4426950408889634f)); }
+#else
+PINN_HD float p_expk(float x, float k) { return std::exp(k * x); }
+#endif
+PINN_HD double p_expk(double x, double k) { return std::exp(k * x); }
 PINN_HD double p_exp(double x) { return std::exp(x); }
 PINN_HD double p_rcp(double x) { return 1.0 / x; }
 PINN_HD double p_rsqrt(double x) { return 1.0 / std::sqrt(x); }
@@ -77,7 +85,7 @@ PINN_HD void act012(T a, T& s, T& s1, T& s2)
         s1 = s - s * s;
         s2 = s1 - T(2) * s * s1;
     } else {
-        s = T(2) * p_rcp(T(1) + p_exp(T(-2) * a)) - T(1);
+        s = T(2) * p_rcp(T(1) + p_expk(a, T(-2))) - T(1);
         s1 = T(1) - s * s;
         s2 = T(-2) * s * s1;
     }

@@ -155,6 +155,24 @@ __device__ __forceinline__ void act012v(f32x4 a, f32x4& s, f32x4& s1, f32x4& s2)
     }
 }
 
+// the same from e2 = log2(e) * (-a) (sigmoid) or log2(e) * (-2a) (tanh): the v_exp_f32 argument itself
+template <int ACT>
+__device__ __forceinline__ void act012v_scaled(f32x4 e2, f32x4& s, f32x4& s1, f32x4& s2)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float rc = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(e2[r]));
+        s[r] = ACT == ACT_SIGMOID ? rc : 2.0f * rc - 1.0f;
+    }
+    if (ACT == ACT_SIGMOID) {
+        s1 = s - s * s;
+        s2 = s1 - 2.0f * s * s1;
+    } else {
+        s1 = 1.0f - s * s;
+        s2 = -2.0f * s * s1;
+    }
+}
+
 template <int ACT>
 __device__ __forceinline__ void act123v(f32x4 s, f32x4& s1, f32x4& s2, f32x4& s3)
 {
@@ -194,6 +212,30 @@ __device__ __forceinline__ float xg_sum(float v)  // sum over the 4 lane groups 
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
+}
+
+// Sums of TWO per-lane values over the 4 lane groups of a point (lanes l, l^16, l^32, l^48) without an
+// LDS round trip (__shfl_xor is ds_bpermute: ~100 cycles of exposed latency per stage).
+// v_permlane32_swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b, so a + b afterwards holds
+// a.lo + a.hi in lanes 0-31 and b.lo + b.hi in lanes 32-63; v_permlane16_swap(t, t') (odd 16-lane rows
+// of t <-> even rows of t') on two copies then adds the two rows of each half.  Result: the total of
+// `a` in lane groups 0 and 1, the total of `b` in lane groups 2 and 3 (returned in one register).
+// The s_nop are the VALU-write -> permlane-read wait states, which hipcc does not pad inside asm.
+__device__ __forceinline__ float xg_sum_pair(float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float t = a + b, u = t;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(t), "+v"(u));
+    return t + u;
+}
+
+// both totals in every lane: one more half swap of two copies of the paired result
+__device__ __forceinline__ void xg_sum_both(float& a, float& b)
+{
+    float t = xg_sum_pair(a, b), u = t;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(t), "+v"(u));
+    a = t;   // [t.lo, t.lo]: the total of a (lane groups 0, 1 held it)
+    b = u;   // [t.hi, t.hi]: the total of b
 }
 
 __device__ __forceinline__ float row16_sum(float v)  // sum over the 16 points of a lane group
@@ -1088,6 +1130,10 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     // per-lane constants of the own neurons (registers for the whole kernel)
     const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW0a + n0), w1 = *reinterpret_cast<const f32x4*>(sW0b + n0);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb0 + n0), b1 = *reinterpret_cast<const f32x4*>(sb1 + n0);
+    // layer 0 only needs the ACTIVATION of its value stream, never the pre-activation itself: fold the
+    // exponent scaling of the activation (exp(-a) / exp(-2a) as exp2) into its weights and bias once
+    constexpr float kEx = (ACT == ACT_SIGMOID ? -1.0f : -2.0f) * 1.4426950408889634f;
+    const f32x4 w0e = w0 * kEx, w1e = w1 * kEx, b0e = b0 * kEx;
     const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + n0);
     const float bout = sbo[0];
     const lds_p wfwd = lds0 + (size_t)(part * KC) * 1024 + lane16;             // + kc * 1024
@@ -1131,9 +1177,40 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
 
+    // -DPINN_STAMPS (diagnostic build, tools/stamps.py): per-wave cycle totals of the phases and of the
+    // barrier waits between them, written to the buffer passed in A.psi (unused by this mode)
+#ifdef PINN_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define T2_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define T2_STAMP(i) do { } while (0)
+#endif
+    // D[own 16 rows][2 passes x NST column tiles] += W[own rows][H] x B, B fragments from the pass buffers
+    // at eb, eb + EB: groups of 4 MFMAs (one pass of one k chunk), the operands of group j+1 requested
+    // before the MFMAs of group j issue
+    auto gemm8 = [&](lds_p wbase, lds_p eb, f32x4 (&d)[2][NST]) {
+        constexpr int NG = 2 * KC;
+        bf16x8 w[2], x[2][NST];
+        auto fetch = [&](int j, bf16x8 (&xx)[NST]) {
+            const int kc = j >> 1, ps = j & 1;
+            if (ps == 0) w[kc & 1] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(wbase + kc * 1024);
+#pragma unroll
+            for (int s = 0; s < NST; s++) xx[s] = bfrag(eb + ps * EB, kc, s);
+        };
+        fetch(0, x[0]);
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            if (j + 1 < NG) fetch(j + 1, x[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NST; s++) d[j & 1][s] = mfma(w[(j >> 1) & 1], x[j & 1][s], d[j & 1][s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     PointRec nxt = load_rec(0);
     int xset = 0;
     for (int64_t itx = 0; itx < iters; itx++) {
+        T2_STAMP(7);
         const int64_t tile = itx * gridDim.x + blockIdx.x;
         const int64_t idx = tile * 16 + c;
         const bool valid = tile < ntile && idx < A.n;
@@ -1156,10 +1233,9 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         for (int ps = 0; ps < 2; ps++) {
             f32x4 a[NST];
 #pragma unroll
-            for (int s = 0; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
-            a[0] += b0;
+            for (int s = 1; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
             f32x4 s0, s1, s2;
-            act012v<ACT>(a[0], s0, s1, s2);
+            act012v_scaled<ACT>(w0e * inA[ps][0] + w1e * inA[1 - ps][0] + b0e, s0, s1, s2);
             const f32x4 q = a[1] * a[1] + a[2] * a[2];
             h0[ps] = s0;
             put(XB + ps * EB, 0, s0);
@@ -1167,7 +1243,9 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             put(XB + ps * EB, 2, s1 * a[2]);
             put(XB + ps * EB, SLP, s1 * a[SLP] + s2 * q);
         }
+        T2_STAMP(0);
         __syncthreads();
+        T2_STAMP(1);
         // ================= P2: layer-1 GEMM over both passes, activations, output partial sums =================
         {
             f32x4 acc[2][NST];
@@ -1177,14 +1255,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
 #pragma unroll
                 for (int s = 1; s < NST; s++) acc[ps][s] = splat(0.f);
             }
-#pragma unroll
-            for (int kc = 0; kc < KC; kc++) {
-                const bf16x8 w = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(wfwd + kc * 1024);
-#pragma unroll
-                for (int ps = 0; ps < 2; ps++)
-#pragma unroll
-                    for (int s = 0; s < NST; s++) acc[ps][s] = mfma(w, bfrag(XB + ps * EB, kc, s), acc[ps][s]);
-            }
+            gemm8(wfwd, XB, acc);
             float Sv = 0.f, Sl = 0.f;
 #pragma unroll
             for (int ps = 0; ps < 2; ps++) {
@@ -1199,11 +1270,12 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 Sv += pw * dot4(wo, s0);
                 Sl += pw * dot4(wo, ol);
             }
-            Sv = xg_sum(Sv);
-            Sl = xg_sum(Sl);
-            if (g == 0) { SB[(part * 16 + c) * 2] = Sv; SB[(part * 16 + c) * 2 + 1] = Sl; }
+            const float tot = xg_sum_pair(Sv, Sl);          // Sv in lane groups 0,1; Sl in groups 2,3
+            if ((g & 1) == 0) SB[(part * 16 + c) * 2 + (g >> 1)] = tot;
         }
+        T2_STAMP(2);
         __syncthreads();
+        T2_STAMP(3);
         // ================= P3: tail, last hidden layer's adjoints of both passes =================
         Tail<float> t;
         {
@@ -1236,30 +1308,39 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             put(YB + ps * EB, 2, u * sv[ps][2]);
             put(YB + ps * EB, SLP, s1 * ol);
         }
+        T2_STAMP(4);
         __syncthreads();
+        T2_STAMP(5);
         // ================= P4: weight gradient, input-adjoint GEMM, layer-0 adjoints =================
+        {   // K = 128 columns = 4 steps (pass, stream pair) x HT column tiles, in groups of 4 MFMAs; the
+            // fragments of group j+1 are requested before the MFMAs of group j issue (the fences pin that
+            // order: otherwise every MFMA sits behind the LDS round trip of its own operands)
+            constexpr int GPK = HT / 4, NG = NST * GPK;          // groups per K step, groups in all
+            bf16x8 fy[2], fx[2][4];
+            auto fetch = [&](int j, bf16x8 (&x)[4]) {
+                const int k = j / GPK, i0 = (j % GPK) * 4;
+                if (j % GPK == 0) fy[k & 1] = trfrag(YB + (k >> 1) * EB, part, k & 1);
 #pragma unroll
-        for (int ps = 0; ps < 2; ps++)
+                for (int i = 0; i < 4; i++) x[i] = trfrag(XB + (k >> 1) * EB, i0 + i, k & 1);
+            };
+            fetch(0, fx[0]);
 #pragma unroll
-            for (int ph = 0; ph < NST / 2; ph++) {
-                const bf16x8 fy = trfrag(YB + ps * EB, part, ph);
+            for (int j = 0; j < NG; j++) {
+                if (j + 1 < NG) fetch(j + 1, fx[(j + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int k = j / GPK, i0 = (j % GPK) * 4;
 #pragma unroll
-                for (int it = 0; it < HT; it++) wacc[it] = mfma(fy, trfrag(XB + ps * EB, it, ph), wacc[it]);
+                for (int i = 0; i < 4; i++) wacc[i0 + i] = mfma(fy[k & 1], fx[j & 1][i], wacc[i0 + i]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
         {
             f32x4 ob[2][NST];
 #pragma unroll
             for (int ps = 0; ps < 2; ps++)
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[ps][s] = splat(0.f);
-#pragma unroll
-            for (int kc = 0; kc < KC; kc++) {
-                const bf16x8 w = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(wbwd + kc * 1024);
-#pragma unroll
-                for (int ps = 0; ps < 2; ps++)
-#pragma unroll
-                    for (int s = 0; s < NST; s++) ob[ps][s] = mfma(w, bfrag(YB + ps * EB, kc, s), ob[ps][s]);
-            }
+            gemm8(wbwd, YB, ob);
 #pragma unroll
             for (int ps = 0; ps < 2; ps++) {
                 f32x4 a[NST];
@@ -1281,7 +1362,15 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         }
         if (C::XSETS == 1) __syncthreads();   // one set of layer-output buffers: P1 of the next tile overwrites it
         xset ^= 1;
+        T2_STAMP(6);
     }
+#ifdef PINN_STAMPS
+    if (A.psi && lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.psi) + ((size_t)blockIdx.x * C::WAVES + part) * 8;
+        for (int i = 0; i < 8; i++) dbg[i] = st_acc[i];
+    }
+#endif
+#undef T2_STAMP
     // =========================== block reduction ===========================
     __syncthreads();
     constexpr int PT = Lay::size;
@@ -1757,19 +1846,26 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
     const float lead = g == 0 ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
 
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntile;
-         tile += (int64_t)gridDim.x * kWavesPerBlock) {
+    // the point record of the next tile is requested one trip ahead (nothing waits for it until then)
+    struct PointRec { float x, y, z, R, E, g; unsigned mk; };
+    const int64_t tstep = (int64_t)gridDim.x * kWavesPerBlock;
+    auto load_rec = [&](int64_t tl) {
+        int64_t id = tl * 16 + c;
+        id = (tl < ntile && id < A.n) ? id : A.n - 1;
+        PointRec r;
+        r.x = A.x[id]; r.y = A.y[id]; r.z = A.z[id]; r.R = A.R[id]; r.E = A.E[id]; r.g = A.g[id];
+        r.mk = (MODE != MODE_FWD && A.mask) ? A.mask[id] : 0u;
+        return r;
+    };
+    PointRec nxt = load_rec((int64_t)blockIdx.x * kWavesPerBlock + wave);
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntile; tile += tstep) {
         const int64_t idx = tile * 16 + c;
         const bool valid = idx < A.n;
-        const int64_t id = valid ? idx : A.n - 1;
-        const float xv = A.x[id], yv = A.y[id], zv = A.z[id], Rv = A.R[id];
-        const float Ev = A.E[id], gv = A.g[id];
-        float m1 = 0.f, m2 = 0.f;
-        if (MODE != MODE_FWD && A.mask) {
-            const uint8_t mk = A.mask[id];
-            m1 = float(mk & 1);
-            m2 = float((mk >> 1) & 1);
-        }
+        const PointRec cur = nxt;
+        if (tile + tstep < ntile) nxt = load_rec(tile + tstep);
+        const float xv = cur.x, yv = cur.y, zv = cur.z, Rv = cur.R;
+        const float Ev = cur.E, gv = cur.g;
+        const float m1 = float(cur.mk & 1), m2 = float((cur.mk >> 1) & 1);
         float inA[2][NST], ri1, ri2;
         {
             const float rho2 = yv * yv + zv * zv, rho = __builtin_amdgcn_sqrtf(rho2);
@@ -1830,10 +1926,10 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             sv[ps][0] = s0;
 #pragma unroll
             for (int s = 1; s < NST; s++) sv[ps][s] = a1[s];
-            const float Sv = xg_sum(dot4(wo, s0)), Sl = xg_sum(dot4(wo, ol));
-            SvT += (useB ? A.P : 1.0f) * Sv;
-            SlT += (useB ? A.P : 1.0f) * Sl;
+            SvT += (useB ? A.P : 1.0f) * dot4(wo, s0);    // lane-local partial sums of both passes ...
+            SlT += (useB ? A.P : 1.0f) * dot4(wo, ol);
         }
+        xg_sum_both(SvT, SlT);                            // ... summed over the point's 4 lane groups once
         Tail<float> t;
         tail<float>(A.out_scale * SvT + bout, A.out_scale * SlT, gv, Ev, F, lapF, ri1 + ri2, A.a, A.b, A.c, m1,
                     m2, A.invN, invN1, invN2, valid ? 1.0f : 0.0f, t);
@@ -2093,7 +2189,7 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
             return launch2_HL<128, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         return false;
     }
-    if (L == 2 && npass == 2 && mode == MODE_BWD && mfma_variant() != 3 && (H == 64 || (H == 128 && mfma_variant() == 4))) {
+    if (L == 2 && npass == 2 && mode == MODE_BWD && mfma_variant() != 3 && (H == 64 || H == 128)) {
         // the benchmark's shape: both passes swept together (k_trunk2)
         if (H == 64) *err = act == ACT_TANH ? launch_trunk2_t<64, ACT_TANH>(theta, wpk, A, grid, st)
                                             : launch_trunk2_t<64, ACT_SIGMOID>(theta, wpk, A, grid, st);

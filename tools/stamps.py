@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Phase-by-phase cycle breakdown of k_trunk2 from a DIAGNOSTIC build with in-kernel s_memtime stamps.
+
+    python tools/stamps.py --build        # here (no GPU): libpinn_hip_stamps.so with -DPINN_STAMPS
+    python tools/stamps.py [--arch wide64] [--points 1000000]     # on the GPU box
+
+The stamped kernel is ~10 % slower (the stamps themselves); what is read from it is the SPLIT of a trip
+between the four phases and the three barrier waits, per wave, averaged over the waves of the grid."""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pinn_for_quantum_wavefunction_surfaces_amd")
+SO = os.path.join(PKG, "libpinn_hip_stamps.so")
+
+
+def build():
+    srcs = ["pinn_kernels.hip", "pinn_trunk_mfma.hip", "pinn_xchg.hip"]
+    objs = []
+    for s in srcs:
+        o = os.path.join(PKG, "build", s.replace(".hip", ".stamps.o"))
+        extra = ["-fno-slp-vectorize"] if s == "pinn_kernels.hip" else []
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
+                               "-Wno-unused-value", "-DPINN_STAMPS"] + extra + ["-c", "-o", o, s],
+                              cwd=os.path.join(PKG, "csrc"))
+        objs.append(o)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
+    print(SO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--arch", default="wide64")
+    ap.add_argument("--points", type=int, default=1000000)
+    args = ap.parse_args()
+    if args.build:
+        return build()
+    os.environ["PINN_HIP_LIB"] = SO
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    sys.argv = ["bench.py"]
+    spec.loader.exec_module(bench)
+    import pinn_for_quantum_wavefunction_surfaces_amd as pkg
+    a = bench.ARCHS[args.arch]
+    dev = torch.device("cuda", 0)
+    params = pkg.set_params()
+    torch.manual_seed(12345)
+    m = pkg.NN_ion(params, a["H"], a["HE"], a["HG"], n_hidden=a["L"], act=a["act_name"], precision=a["precision"]).to(dev)
+    tr = pkg.Trainer(m, params, n_points=args.points, lr=8e-3, seed=12345, device=dev)
+    waves = a["H"] // 16
+    dbg = torch.zeros(4096 * waves * 8, device=dev, dtype=torch.int64)
+    for _ in range(50):
+        tr.step()
+    torch.cuda.synchronize()
+    os.environ["PINN_STAMP_PTR"] = "%x" % dbg.data_ptr()
+    tr.h.profile_enable(4)
+    for _ in range(4):
+        tr.step()
+    torch.cuda.synchronize()
+    ms = tr.h.profile_read(4)
+    d = dbg.cpu().numpy().reshape(-1, 8)
+    d = d[d.sum(1) > 0].astype(np.float64)
+    trips = (args.points + 15) // 16 / (d.shape[0] / waves)
+    names = ["P1 inputs+layer0", "barrier 1", "P2 gemm+act", "barrier 2", "P3 tail+last hidden", "barrier 3",
+             "P4 wgrad+adjoint+layer0", "loop top"]
+    tot = d.sum(1).mean()
+    print("%s: stamped kernel %.4f ms, %d waves, %.1f trips per wave, %.0f cycles per trip (%.2f GHz implied)" % (
+        args.arch, ms, d.shape[0], trips, tot / trips, tot / (ms * 1e6)))
+    for i in (7, 0, 1, 2, 3, 4, 5, 6):
+        print("  %-26s %7.0f cycles per trip  %5.1f %%   (min wave %.0f, max wave %.0f)" % (
+            names[i], d[:, i].mean() / trips, 100 * d[:, i].mean() / tot, d[:, i].min() / trips, d[:, i].max() / trips))
+
+
+if __name__ == "__main__":
+    main()

@@ -50,10 +50,14 @@ def energy_from_psi(Ri, params, model):
     return E_int, float(o["E"][-1])
 
 
-def energy_from_psi_LCAO(Ri, params):
-    """LCAO reference curve psi = f1 + f2 (poc/main.py:467-492), closed form Laplacian."""
+def energy_from_psi_LCAO(Ri, params, device=None):
+    """LCAO reference curve psi = f1 + f2 (poc/main.py:467-492), closed form Laplacian; evaluated
+    and integrated on `device` (default: the GPU when there is one -- a 250^3 grid in fp64 is
+    no work for it -- else the CPU: this curve involves no kernel of the library)."""
     n = int(params["n_test"])
-    ax, (x, y, z) = _grid(params, n, "cpu")
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    ax, (x, y, z) = _grid(params, n, device)
     x, y, z = x.double(), y.double(), z.double()
     r1 = torch.sqrt((x - Ri) ** 2 + y ** 2 + z ** 2)
     r2 = torch.sqrt((x + Ri) ** 2 + y ** 2 + z ** 2)
@@ -118,5 +122,5 @@ def calculate_E_R(params, model=None):
     out = {"R": Rs, "E_int": np.zeros(len(Rs)), "Elcao": np.zeros(len(Rs)), "E_net": np.zeros(len(Rs))}
     for i, Ri in enumerate(Rs):
         out["E_int"][i], out["E_net"][i] = energy_from_psi(float(Ri), params, model)
-        out["Elcao"][i] = energy_from_psi_LCAO(float(Ri), params)
+        out["Elcao"][i] = energy_from_psi_LCAO(float(Ri), params, device=next(model.parameters()).device)
     return out

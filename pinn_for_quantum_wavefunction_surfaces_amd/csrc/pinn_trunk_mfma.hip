@@ -1028,11 +1028,13 @@ hipError_t launch2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int gr
     size_t lds = C::LDS_BYTES;
     const size_t need = C::GROUPS == 1 ? 64 : (size_t)(TrunkLayout<H, L>::size + 16) * 4;
     if (lds < need) lds = need;
-    static bool attr_set = false;   // once per instantiation: not a stream operation (graph capture)
-    if (!attr_set) {
+    static bool attr_set[64] = {};   // once per instantiation and device: not a stream operation (graph capture)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, theta, (const __bf16*)wpk, A);
     return hipGetLastError();
@@ -2205,6 +2207,9 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
     }
     if (H == 128 && L == 2) return launch2_HL<128, 2, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (H == 64 && L == 4) return launch2_HL<64, 4, 2, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-    if (H == 128 && L == 4) return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+    if (H == 128 && L == 4) {
+        if (mfma_variant() == 5) return launch2_HL<128, 4, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
+        return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+    }
     return false;
 }

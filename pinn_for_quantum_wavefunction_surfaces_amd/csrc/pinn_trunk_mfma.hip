@@ -616,9 +616,10 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
                 if (WSTREAM) wuse++;
             }
             // ---- combine the partial output sums of the group's waves (fixed order)
-            Sv = xg_sum(Sv);
-            Sl = xg_sum(Sl);
-            if (g == 0) { SB[(part * 16 + c) * 2] = Sv; SB[(part * 16 + c) * 2 + 1] = Sl; }
+            {
+                const float tot = xg_sum_pair(Sv, Sl);      // Sv in lane groups 0,1; Sl in groups 2,3 (no LDS trip)
+                if ((g & 1) == 0) SB[(part * 16 + c) * 2 + (g >> 1)] = tot;
+            }
             __syncthreads();
             Sv = 0.f; Sl = 0.f;
 #pragma unroll
@@ -1810,16 +1811,31 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
     __bf16* Xl = Xh + IMG;
 
     // ---- per-lane constants: the own neurons' first-layer rows, biases, output weights
-    f32x4 w0a, w0b, b0, b1, wo;
+    // (the symmetric reverse kernel sits at its 256-register cap: there the biases and output weights are
+    // re-read from a 192-byte LDS table where they are used instead of occupying 12 registers throughout)
+    constexpr bool CLDS = MODE == MODE_BWD && NPASS == 2;
+    __shared__ __attribute__((aligned(16))) float sconst[CLDS ? 48 : 4];
+    f32x4 w0a, w0b, b0r, b1r, wor;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int nj = 4 * g + r;
         w0a[r] = theta[Lay::W(0) + 2 * nj];
         w0b[r] = theta[Lay::W(0) + 2 * nj + 1];
-        b0[r] = theta[Lay::b(0) + nj];
-        b1[r] = theta[Lay::b(1) + nj];
-        wo[r] = theta[Lay::Wout + nj];
+        b0r[r] = theta[Lay::b(0) + nj];
+        b1r[r] = theta[Lay::b(1) + nj];
+        wor[r] = theta[Lay::Wout + nj];
     }
+    if (CLDS) {
+        if (threadIdx.x < 16) {
+            sconst[threadIdx.x] = theta[Lay::b(0) + threadIdx.x];
+            sconst[16 + threadIdx.x] = theta[Lay::b(1) + threadIdx.x];
+            sconst[32 + threadIdx.x] = theta[Lay::Wout + threadIdx.x];
+        }
+        __syncthreads();
+    }
+#define T16_B0 (CLDS ? *reinterpret_cast<const f32x4*>(sconst + 4 * g) : b0r)
+#define T16_B1 (CLDS ? *reinterpret_cast<const f32x4*>(sconst + 16 + 4 * g) : b1r)
+#define T16_WO (CLDS ? *reinterpret_cast<const f32x4*>(sconst + 32 + 4 * g) : wor)
     const float bout = theta[Lay::bout];
     // A fragments of the 16 x 16 layer: forward W1[c][4g + j] in three pieces, reverse W1[4g + j][c] in two
     s16x4 Fh, Fm, Fl, Th, Tl;
@@ -1895,7 +1911,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             f32x4 a0[NST], ox[NST];
 #pragma unroll
             for (int s = 0; s < NST; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
-            a0[0] += b0;
+            a0[0] += T16_B0;
             {
                 f32x4 s0, s1, s2;
                 act012v<ACT>(a0[0], s0, s1, s2);
@@ -1920,7 +1936,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
                 acc = mfma16(Fh, as_s4(pm), acc);
                 a1[s] = mfma16(Fh, as_s4(ph), acc);
             }
-            a1[0] += b1;
+            a1[0] += T16_B1;
             f32x4 s0, s1, s2;
             act012v<ACT>(a1[0], s0, s1, s2);
             const f32x4 q = a1[1] * a1[1] + a1[2] * a1[2];
@@ -1928,6 +1944,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             sv[ps][0] = s0;
 #pragma unroll
             for (int s = 1; s < NST; s++) sv[ps][s] = a1[s];
+            const f32x4 wo = T16_WO;
             SvT += (useB ? A.P : 1.0f) * dot4(wo, s0);    // lane-local partial sums of both passes ...
             SlT += (useB ? A.P : 1.0f) * dot4(wo, ol);
         }
@@ -1968,6 +1985,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
                 act123v<ACT>(h, s1, s2, s3);
                 const f32x4 q = a1x * a1x + a1r * a1r;
                 woacc += cv * h + cl * (s1 * a1l + s2 * q);
+                const f32x4 wo = T16_WO;
                 const f32x4 o0 = cv * wo, olb = cl * wo;
                 const f32x4 u = 2.0f * s2 * olb;
                 yo[SLP] = s1 * olb;
@@ -2076,6 +2094,9 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
     }
     if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
 }
+#undef T16_B0
+#undef T16_B1
+#undef T16_WO
 
 template <int ACT, int NPASS>
 hipError_t launch_trunk16_t(int mode, const float* theta, const TrunkArgs& A, int grid, hipStream_t st)

@@ -118,10 +118,12 @@ ARCHS["wide4x128x3"] = dict(ARCHS["wide4x128"], precision="bf16x3", dtype="bf16x
                             label="BASELINE config 1: 4x128 tanh trunk + 2x32 E-net + 1x10 gate, fp32-grade "
                                   "(split-bf16 MFMA trunk: hi+lo operands, 3 MFMAs per product, fp32 accumulate "
                                   "and elementwise), 100 000 points/step, seeded random init")
-# HBM bytes per launch of each workload's trunk kernel from rocprofv3 PMC passes (FETCH_SIZE x 2 --
-# the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r01zz_final_default_bench.md)
-TRAFFIC = {"wide64": 71.7e6, "wide64x3": 40.1e6, "ref16": 79.2e6, "wide128": 81.4e6}
-TRAFFIC_SOURCE = "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r01zz"
+# HBM bytes per launch of each workload's trunk kernel from this round's rocprofv3 PMC passes (FETCH_SIZE x 2 --
+# the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r02_default_bench.md).  The 4x128
+# split-bf16 kernel still spills (560 B/lane): most of its traffic is scratch.
+TRAFFIC = {"wide64": 71.7e6, "wide64x3": 40.1e6, "ref16": 41.3e6, "ref16ft": 34.7e6, "wide128": 80.3e6,
+           "wide4x128x3": 2280e6}
+TRAFFIC_SOURCE = "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r02_default_bench.md"
 DEFAULT_ARCH = "wide64"
 SECONDARY = {"wide64": ["wide64x3", "wide4x128x3", "ref16", "ref16ft", "wide128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
              "wide128": ["wide128x3"], "wide128x3": ["wide128"]}

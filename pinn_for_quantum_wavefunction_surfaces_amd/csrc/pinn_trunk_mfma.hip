@@ -1,15 +1,15 @@
-// pinn_trunk_mfma.hip -- fused trunk kernels for wide architectures on the bf16 matrix cores.
+// pinn_trunk_mfma.hip -- fused trunk kernels on the bf16 matrix cores.
 //
-// Same mathematics as k_trunk in pinn_kernels.hip (five streams per neuron, hand-derived
-// adjoint; train.py:41-57,71 / poc/main.py:247-303,341-355,403), different execution shape:
-// at H >= 64 the H x H layers are dense GEMMs, so they run on v_mfma_f32_16x16x32_bf16.
+// Same mathematics as k_trunk in pinn_kernels.hip (streams per neuron, hand-derived adjoint;
+// train.py:41-57,71 / poc/main.py:247-303,341-355,403), different execution shape: the H x H layers
+// are dense GEMMs, so they run on v_mfma_f32_16x16x32_bf16 (16x16x16 for the 16-wide trunk), and the
+// streams are FOUR (value, d/dx, d/drho, Laplacian: see NST below), not the five Cartesian ones.
 //
-// Common to both kernels below:
-//   * every GEMM is computed transposed, D[neuron][column] with column = (stream, point):
-//     the five streams of one point are five 16-column tiles, so lane (g = lane>>4,
-//     c = lane&15) holds, for point c, the neurons 16*jt + 4*g + r (r = 0..3) of a row
-//     tile jt and all five streams of them in its own registers: activation and adjoint
-//     algebra are purely lane-local.
+// Common to the kernels below:
+//   * every GEMM is computed transposed, D[neuron][column] with column = (stream, point): the
+//     streams of one point are 16-column tiles, so lane (g = lane>>4, c = lane&15) holds, for point
+//     c, the neurons 16*jt + 4*g + r (r = 0..3) of a row tile jt and all streams of them in its own
+//     registers: activation and adjoint algebra are purely lane-local.
 //   * the accumulator layout of one layer IS the B-operand layout of the next (and of the
 //     reverse pass): a lane's 8 bf16 of a k-chunk are its 4 neurons of row tiles 2kc and
 //     2kc+1.  That fixes a permutation of the contraction index, applied once to the
@@ -19,19 +19,19 @@
 //     input) B-fragments are read back transposed with ds_read_b64_tr_b16 as MFMA operands;
 //     gradient tiles accumulate in registers for the whole kernel.  Vector gradients (biases,
 //     w_out, the 2-column first layer) are lane-local running sums, reduced once at the end.
-//   * the forward state of BOTH passes of the symmetric double pass stays resident, so the
-//     reverse sweeps (pass B, then pass A) never re-evaluate a pass.
 //   * per-block partials, fixed-order second stage (k_reduce): bitwise reproducible.
 //
-// k_trunk_mfma  ("point-split", 2x64 only, an A/B alternative): a wave owns 16 points and ALL
-//   neurons; activations never leave registers between layers; LDS only for the weights and
-//   the weight-gradient transposes.
-// k_trunk_mfma2 ("neuron-split", every default): SPLIT waves share a 16-point tile, each
-//   owning 16 or 32 neurons; layer outputs and adjoints are exchanged through LDS buffers in
-//   B-fragment order, which double as the transposed-read image of the weight gradient.
-//   Options per shape (M2Cfg): resident blocks per CU, both-pass buffers (KEEP), operand
-//   prefetch (PIPE), fp32 saved state (SVF32), weights streamed through LDS by LDS-DMA
-//   (WSTREAM), split-bf16 operands (X3: hi + lo planes, three MFMAs per product).
+// k_trunk2      two hidden layers, symmetric double pass, full reverse sweep (the benchmark's shape,
+//   H = 64 and 128, bf16): H/16 waves share a 16-point tile, both passes swept together.
+// k_trunk_mfma2 every other wide shape and mode (L = 4, single pass, forward-only, frozen trunk,
+//   split-bf16): SPLIT waves share a 16-point tile, each owning 16 or 32 neurons, pass by pass;
+//   layer outputs and adjoints are exchanged through LDS buffers in B-fragment order, which double
+//   as the transposed-read image of the weight gradient.  Options per shape (M2Cfg): resident
+//   blocks per CU, both-pass buffers (KEEP), operand prefetch (PIPE), fp32 saved state (SVF32),
+//   weights streamed through LDS by LDS-DMA (WSTREAM), split-bf16 operands (X3: hi + lo planes,
+//   three MFMAs per product), one layer-output buffer rebuilt in the reverse sweep (XONE).
+// k_trunk16     the reference's 16-wide trunk (fp32-grade: three-piece split-bf16 forward).
+// k_rnet_mfma_fwd / _bwd   E-net and gate.
 //
 // Precision: bf16 MFMA operands (activations, adjoints, weights), fp32 accumulation and
 // fp32 elementwise math.  Tolerances are stated in tests/test_gpu_parity.py; plain bf16 is
@@ -2169,8 +2169,8 @@ bool mfma_x3_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 |
 
 // resident blocks per CU the chosen decomposition is built for (pinn_create sizes the persistent
 // grid and the per-block partial buffer with it)
-// measurement switch (tools/kbench.py): PINN_MFMA_VARIANT = 0 (default decomposition) or an alternative
-// instantiation of the same kernel; read at pinn_create (grid sizing) and at every launch
+// measurement switch (tools/kbench.py): PINN_MFMA_VARIANT = 0 (default) or 3 (the per-pass kernel
+// k_trunk_mfma2 where k_trunk2 is the default); read at every launch
 static int mfma_variant()
 {
     const char* e = getenv("PINN_MFMA_VARIANT");
@@ -2179,8 +2179,7 @@ static int mfma_variant()
 
 int mfma_blocks_per_cu(int H, int L, bool x3)
 {
-    const int v = mfma_variant();
-    if (H == 64 && L == 2 && !x3) return v == 1 ? 3 : (v == 2 ? 1 : 2);
+    if (H == 64 && L == 2 && !x3) return 2;
     return 1;
 }
 
@@ -2197,6 +2196,7 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
     // blocks per CU.  One decomposition per shape, the fastest measured (round 1, 1M points, kernel ms):
     //   2x64 : <4,4> x 2 blocks/CU 0.72 (<4,8> 0.74, <2,8> spills)     2x128: <8,8> 1.88 (<4,4> 2.7)
     //   4x64 : <2,4> 2.27 (<4,8> 4.2)                                   4x128: <4,4> 11.8 (<8,8> 15.4)
+    // (round 2, four streams: 2x64 0.57, 3 blocks/CU 0.69, <4,8> 0.58; 4x128 <4,4> 7.6, <8,8> 8.3)
     if (x3) {   // split-bf16 operands (3 MFMAs per product): neuron-split kernel only
         if (H == 64 && L == 2) {
             return launch2_HL<64, 2, 4, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
@@ -2220,17 +2220,9 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
                                     : launch_trunk2_t<128, ACT_SIGMOID>(theta, wpk, A, grid, st);
         return true;
     }
-    if (H == 64 && L == 2) {
-        const int v = mfma_variant();
-        if (v == 1) return launch2_HL<64, 2, 4, 4, false, 3>(act, npass, mode, theta, wpk, A, grid, st, err);
-        if (v == 2) return launch2_HL<64, 2, 4, 8, false, 1>(act, npass, mode, theta, wpk, A, grid, st, err);
-        return launch2_HL<64, 2, 4, 4, false, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
-    }
+    if (H == 64 && L == 2) return launch2_HL<64, 2, 4, 4, false, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (H == 128 && L == 2) return launch2_HL<128, 2, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (H == 64 && L == 4) return launch2_HL<64, 4, 2, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-    if (H == 128 && L == 4) {
-        if (mfma_variant() == 5) return launch2_HL<128, 4, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
-        return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-    }
+    if (H == 128 && L == 4) return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
     return false;
 }

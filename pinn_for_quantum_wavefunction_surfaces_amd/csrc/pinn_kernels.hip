@@ -805,17 +805,26 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
                                                float* __restrict__ best_theta,
                                                float* __restrict__ best_loss)
 {
-    const int step = *step_count + 1;
+    // the bias corrections are formed in double and rounded once, as torch does for fp32 tensors -- by ONE
+    // thread (two double pow() per thread were most of this kernel's 10 us), handed out through LDS
+    __shared__ float sh_step_size, sh_inv_bc2s;
+    __shared__ int sh_step, sh_better;
+    if (threadIdx.x == 0) {
+        const int step0 = *step_count + 1;
+        const double bc1 = 1.0 - pow(b1d, (double)step0);
+        const double bc2 = 1.0 - pow(b2d, (double)step0);
+        sh_step_size = (float)(lr / bc1);
+        sh_inv_bc2s = (float)(1.0 / sqrt(bc2));
+        sh_step = step0;
+        sh_better = best_loss != nullptr && (grad[P] + grad[P + 1] + grad[P + 2]) < *best_loss;
+    }
+    __syncthreads();  // thread 0 has read step_count / best_loss before anything is written
+    const int step = sh_step;
     const float ltot = grad[P] + grad[P + 1] + grad[P + 2];
-    const bool better = best_loss != nullptr && ltot < *best_loss;
-    // scalars are formed in double and rounded once, as torch does for fp32 tensors
-    const double bc1 = 1.0 - pow(b1d, (double)step);
-    const double bc2 = 1.0 - pow(b2d, (double)step);
-    const float step_size = (float)(lr / bc1);
-    const float inv_bc2s = (float)(1.0 / sqrt(bc2));
+    const bool better = sh_better != 0;
+    const float step_size = sh_step_size, inv_bc2s = sh_inv_bc2s;
     const float b1 = (float)b1d, b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
     const float eps = (float)epsd;
-    __syncthreads();  // every thread has read step_count / best_loss
     for (int k = threadIdx.x; k < P; k += blockDim.x) {
         const float th = theta[k];
         if (better && best_theta) best_theta[k] = th;  // train.py:58-60: params the loss was taken at

@@ -1064,7 +1064,8 @@ bool launch2_HL(int act, int npass, int mode, const float* theta, __bf16* wpk, c
 // with BOTH passes of the double pass swept together.  Same decomposition as k_trunk_mfma2 (H/16 waves
 // share a 16-point tile, each owning 16 neurons; B fragments exchanged through LDS in operand order),
 // but every phase handles the 2 x NST x 16 = 128 (pass, stream, point) columns of the tile at once:
-//   P1  point record (requested one trip ahead), orbitals, layer 0 of both passes -> XB[A], XB[B]
+//   P1  point record (orbitals, E, g, mask: from an LDS ring filled 4 tiles per wave at a time, the raw
+//       points of the next fill requested a whole ring ahead), layer 0 of both passes -> XB[A], XB[B]
 //   P2  layer-1 GEMM over 128 columns (each weight fragment feeds 8 MFMAs), activations of both
 //       passes, partial output sums -> SB
 //   P3  tail (psi, residual, loss seeds), last-hidden adjoints of both passes -> YB[A], YB[B]
@@ -1080,12 +1081,18 @@ struct T2Cfg {
     static constexpr int EB = KC * NST * 64 * 16;                 // bytes of one (pass) exchange buffer
     static constexpr int WBYTES = 2 * H * H * 2;                  // forward + transposed matrix, bf16
     static constexpr int NSMALL = 3 * H + H + H + 4;              // W0a W0b b0 | b1 | wout | bout
-    static constexpr int XSETS = (OCC * (WBYTES + NSMALL * 4 + 6 * EB + 1024) <= 160 * 1024) ? 2 : 1;
+    // point-record ring: the orbitals (and E, g, mask) of the block's next RB tiles, 12 floats per point,
+    // computed 64 points per wave at a time -- without it every one of the tile's WAVES waves (and each of
+    // its 4 lane groups) computes the same 16 points' orbitals in every trip
+    static constexpr int RB = 4 * WAVES, RECF = 12;
+    static constexpr int RBYTES = RB * 16 * RECF * 4;
+    static constexpr int XSETS = (OCC * (WBYTES + NSMALL * 4 + 6 * EB + RBYTES + 1024) <= 160 * 1024) ? 2 : 1;
     static constexpr size_t OFF_SMALL = WBYTES;
     static constexpr size_t OFF_X = OFF_SMALL + NSMALL * 4;
     static constexpr size_t OFF_Y = OFF_X + (size_t)XSETS * 2 * EB;
     static constexpr size_t OFF_S = OFF_Y + 2 * EB;
-    static constexpr size_t LDS_BYTES = OFF_S + WAVES * 16 * 2 * 4;
+    static constexpr size_t OFF_R = OFF_S + WAVES * 16 * 2 * 4;
+    static constexpr size_t LDS_BYTES = OFF_R + RBYTES;
     static_assert(OCC * LDS_BYTES <= 160 * 1024, "k_trunk2 does not fit the CU's LDS");
 };
 
@@ -1157,15 +1164,28 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     const int64_t ntile = (A.n + 15) / 16;
     const int64_t iters = (ntile + gridDim.x - 1) / gridDim.x;   // same for every block: barriers match
 
+    // ring batch b covers trips b*RB .. b*RB + RB-1; this lane's point of it: trip b*RB + 4*part + g, column c
+    constexpr int RB = C::RB, RECF = C::RECF;
+    float* ring = reinterpret_cast<float*>(lds_raw + C::OFF_R);
     struct PointRec { float x, y, z, R, E, g; unsigned mk; };
-    auto load_rec = [&](int64_t itn) {
-        const int64_t tl = itn * gridDim.x + blockIdx.x;
+    auto load_rec = [&](int64_t b) {
+        const int64_t tl = (b * RB + 4 * part + g) * gridDim.x + blockIdx.x;
         int64_t id = tl * 16 + c;
         id = (tl < ntile && id < A.n) ? id : A.n - 1;
         PointRec r;
         r.x = A.x[id]; r.y = A.y[id]; r.z = A.z[id]; r.R = A.R[id]; r.E = A.E[id]; r.g = A.g[id];
         r.mk = A.mask ? A.mask[id] : 0u;
         return r;
+    };
+    auto fill_ring = [&](const PointRec& r) {
+        float i0[NST], i1[NST], ri1, ri2;
+        const float rho2 = r.y * r.y + r.z * r.z, rho = __builtin_amdgcn_sqrtf(rho2);
+        orbital_cyl<float>(r.x - r.R, rho2, rho, i0, ri1);
+        orbital_cyl<float>(r.x + r.R, rho2, rho, i1, ri2);
+        float* d = ring + ((4 * part + g) * 16 + c) * RECF;
+        *reinterpret_cast<f32x4*>(d) = f32x4{i0[0], i0[1], i0[2], i0[3]};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{i1[0], i1[1], i1[2], i1[3]};
+        *reinterpret_cast<f32x4*>(d + 8) = f32x4{ri1 + ri2, r.E, r.g, (float)r.mk};   // mask bits as 0.0 .. 3.0
     };
     auto put = [&](lds_p eb, int s, f32x4 v) {      // own 4 neurons of stream s -> 8 bytes of the B fragment
         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + own_slot + s * 1024) = pack4(v);
@@ -1217,16 +1237,26 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         const int64_t tile = itx * gridDim.x + blockIdx.x;
         const int64_t idx = tile * 16 + c;
         const bool valid = tile < ntile && idx < A.n;
-        const PointRec cur = nxt;
-        if (itx + 1 < iters) nxt = load_rec(itx + 1);
+        if (itx % RB == 0) {
+            // refill: the last reads of the previous batch (P1, P3 of the previous trip) lie before that
+            // trip's third barrier, which every wave has passed
+            fill_ring(nxt);
+            nxt = load_rec(itx / RB + 1);       // raw points of the next batch: nothing waits for them for RB trips
+            __syncthreads();
+        }
         const lds_p XB = lds0 + C::OFF_X + (size_t)(C::XSETS == 2 ? xset : 0) * 2 * EB;   // [pass] at + ps * EB
         const lds_p YB = lds0 + C::OFF_Y;
         // ================= P1: inputs and layer 0 of both passes =================
-        float inA[2][NST], ri1, ri2;
+        float inA[2][NST];
+        float Usum, Ept, gpt;
+        unsigned mkpt;
         {
-            const float rho2 = cur.y * cur.y + cur.z * cur.z, rho = __builtin_amdgcn_sqrtf(rho2);
-            orbital_cyl<float>(cur.x - cur.R, rho2, rho, inA[0], ri1);
-            orbital_cyl<float>(cur.x + cur.R, rho2, rho, inA[1], ri2);
+            const float* rp = ring + ((int)(itx % RB) * 16 + c) * RECF;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4),
+                        r2 = *reinterpret_cast<const f32x4*>(rp + 8);
+#pragma unroll
+            for (int s = 0; s < NST; s++) { inA[0][s] = r0[s]; inA[1][s] = r1[s]; }
+            Usum = r2[0]; Ept = r2[1]; gpt = r2[2]; mkpt = (unsigned)r2[3];
         }
         const float F = inA[0][0] + A.P * inA[1][0];
         const float lapF = inA[0][SLP] + A.P * inA[1][SLP];
@@ -1285,8 +1315,8 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             float Sv = 0.f, Sl = 0.f;
 #pragma unroll
             for (int pp = 0; pp < C::WAVES; pp++) { Sv += SB[(pp * 16 + c) * 2]; Sl += SB[(pp * 16 + c) * 2 + 1]; }
-            tail<float>(A.out_scale * Sv + bout, A.out_scale * Sl, cur.g, cur.E, F, lapF, ri1 + ri2, A.a, A.b, A.c,
-                        float(cur.mk & 1), float((cur.mk >> 1) & 1), A.invN, invN1, invN2, valid ? 1.0f : 0.0f, t);
+            tail<float>(A.out_scale * Sv + bout, A.out_scale * Sl, gpt, Ept, F, lapF, Usum, A.a, A.b, A.c,
+                        float(mkpt & 1), float((mkpt >> 1) & 1), A.invN, invN1, invN2, valid ? 1.0f : 0.0f, t);
             if (valid && g == 0 && part == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
             acc_pde += lead * t.l_pde;
             acc_bc1 += lead * t.l_bc1;

@@ -237,6 +237,14 @@ def main():
     rehearsal = os.environ.get("PINN_REHEARSE_ONE_GPU") == "1"
     if rehearsal:
         local_rank = 0
+    # stdout carries ONE line, the JSON record.  Library banners (RCCL prints its version to stdout when the
+    # first communicator is built, gloo its connection notes) would precede it, so in distributed runs file
+    # descriptor 1 points at stderr until the record is written to the saved descriptor.
+    json_fd = None
+    if use_dist:
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -420,7 +428,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(theta0, arch, gpu_check)
             out["parity_observed"] = out["cpu_baseline"].pop("parity_observed")
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out) + "\n"
+        if json_fd is not None:
+            os.write(json_fd, line.encode())
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
     if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -1469,6 +1469,383 @@ hipError_t launch_trunk2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, 
 }
 
 // =====================================================================================
+// k_trunk2x<ACT>: k_trunk2's schedule (both passes swept together, three barriers per tile) for the 2x64
+// trunk in split-bf16, the fp32-grade mode: every MFMA operand is hi + lo (two bf16 planes in the exchange
+// buffers, the lo weight fragments in 16 registers per wave), every product three MFMAs into one fp32
+// accumulator (hi*hi + hi*lo + lo*hi), saved pre-activations fp32.  Two tile groups of four waves per
+// block (one block per CU, two waves per SIMD); the groups share the weights and the barriers, each has its
+// own exchange buffers; their gradient accumulators are added through LDS at the end (fixed order).
+struct T2xCfg {
+    static constexpr int H = 64, HT = 4, KC = 2, WPG = 4, GROUPS = 2, WAVES = 8;
+    static constexpr int EB1 = KC * NST * 64 * 16;                // one plane of one pass buffer
+    static constexpr int EB = 2 * EB1;                            // hi plane, lo plane
+    static constexpr int WBYTES = 2 * H * H * 2;                  // hi plane: forward + transposed matrix
+    static constexpr int NSMALL = 5 * H + 4;                      // W0a W0b b0 | b1 | wout | bout
+    static constexpr size_t OFF_SMALL = WBYTES;
+    static constexpr size_t OFF_G = OFF_SMALL + NSMALL * 4;
+    static constexpr int GBYTES = 2 * EB + 2 * EB + WPG * 16 * 2 * 4;   // XB[2 passes], YB[2 passes], SB
+    static constexpr size_t LDS_BYTES = OFF_G + (size_t)GROUPS * GBYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "k_trunk2x does not fit the CU's LDS");
+};
+
+template <int ACT>
+__global__ __launch_bounds__(T2xCfg::WAVES * 64, 2)
+void k_trunk2x(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, TrunkArgs A)
+{
+    using C = T2xCfg;
+    constexpr int H = C::H, HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB, EB1 = C::EB1;
+    using Lay = TrunkLayout<H, 2>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    typedef __attribute__((address_space(3))) unsigned char* lds_p;
+    const lds_p lds0 = (lds_p)lds_raw;
+    float* small = reinterpret_cast<float*>(lds_raw + C::OFF_SMALL);
+    float* sW0a = small;
+    float* sW0b = small + H;
+    float* sb0 = small + 2 * H;
+    float* sb1 = small + 3 * H;
+    float* swo = small + 4 * H;
+    float* sbo = small + 5 * H;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave / C::WPG, part = wave % C::WPG;
+    const int g = lane >> 4, c = lane & 15;
+    const int lane16 = lane * 16;
+    const int own_slot = lane16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
+    const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
+    const int n0 = 16 * part + 4 * g;
+    const lds_p gbase = lds0 + C::OFF_G + grp * C::GBYTES;
+    const lds_p XB = gbase, YB = gbase + 2 * EB;
+    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_G + (size_t)grp * C::GBYTES + 4 * EB);
+
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(wpk_g);     // hi plane
+        uint4* dst = reinterpret_cast<uint4*>(lds_raw);
+        for (int k = threadIdx.x; k < C::WBYTES / 16; k += NT) dst[k] = src[k];
+        for (int k = threadIdx.x; k < H; k += NT) {
+            sW0a[k] = theta[Lay::W(0) + 2 * k];
+            sW0b[k] = theta[Lay::W(0) + 2 * k + 1];
+            sb0[k] = theta[Lay::b(0) + k];
+            sb1[k] = theta[Lay::b(1) + k];
+            swo[k] = theta[Lay::Wout + k];
+        }
+        if (threadIdx.x == 0) sbo[0] = theta[Lay::bout];
+    }
+    __syncthreads();
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW0a + n0), w1 = *reinterpret_cast<const f32x4*>(sW0b + n0);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb0 + n0), b1 = *reinterpret_cast<const f32x4*>(sb1 + n0);
+    const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + n0);
+    const float bout = sbo[0];
+    const lds_p wfwd = lds0 + (size_t)(part * KC) * 1024 + lane16;
+    const lds_p wbwd = lds0 + (size_t)H * H * 2 + (size_t)(part * KC) * 1024 + lane16;
+    // lo plane of the own weight fragments: registers for the whole kernel (the packed lo plane follows the
+    // hi plane: k_pack_weights<64, 2, true>)
+    bf16x8 wlo_f[KC], wlo_b[KC];
+    {
+        const __bf16* lo = wpk_g + (size_t)2 * H * H;
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            wlo_f[kc] = *reinterpret_cast<const bf16x8*>(lo + ((size_t)(part * KC + kc) * 64 + lane) * 8);
+            wlo_b[kc] = *reinterpret_cast<const bf16x8*>(lo + (size_t)H * H + ((size_t)(part * KC + kc) * 64 + lane) * 8);
+        }
+    }
+
+    f32x4 wacc[HT], bacc0 = splat(0.f), bacc1 = splat(0.f), w0acc0 = splat(0.f), w0acc1 = splat(0.f),
+          woacc = splat(0.f);
+#pragma unroll
+    for (int it = 0; it < HT; it++) wacc[it] = splat(0.f);
+    float acc_bout = 0.f, acc_pde = 0.f, acc_bc1 = 0.f, acc_bc2 = 0.f;
+    float invN1 = A.invN1, invN2 = A.invN2;
+    if (A.bc_counts) {
+        const long long c1 = A.bc_counts[0], c2 = A.bc_counts[1];
+        invN1 = c1 > 0 ? 1.0f / (float)c1 : 0.0f;
+        invN2 = c2 > 0 ? 1.0f / (float)c2 : 0.0f;
+    }
+    const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
+    const int64_t ntile = (A.n + 15) / 16;
+    const int64_t tstride = (int64_t)gridDim.x * C::GROUPS;
+    const int64_t iters = (ntile + tstride - 1) / tstride;       // same for every wave: barriers match
+
+    struct PointRec { float x, y, z, R, E, g; unsigned mk; };
+    auto load_rec = [&](int64_t itn) {
+        const int64_t tl = itn * tstride + (int64_t)blockIdx.x * C::GROUPS + grp;
+        int64_t id = tl * 16 + c;
+        id = (tl < ntile && id < A.n) ? id : A.n - 1;
+        PointRec r;
+        r.x = A.x[id]; r.y = A.y[id]; r.z = A.z[id]; r.R = A.R[id]; r.E = A.E[id]; r.g = A.g[id];
+        r.mk = A.mask ? A.mask[id] : 0u;
+        return r;
+    };
+    auto put = [&](lds_p eb, int s, f32x4 v) {      // own 4 neurons of stream s: hi plane, lo plane
+        u32x2 ph, pl;
+        split4(v, ph, pl);
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + own_slot + s * 1024) = ph;
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + EB1 + own_slot + s * 1024) = pl;
+    };
+    auto bfrag = [&](lds_p eb, int kc, int s) {
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + lane16 + (kc * NST + s) * 1024);
+    };
+    auto trfrag = [&](lds_p eb, int T, int ph) {
+        const lds_p p0 = eb + trl + ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 64));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    // D[own 16 rows][2 passes x NST column tiles] += W x B with split operands: per (k chunk, pass) group the
+    // four hi*hi MFMAs issue first (their B fragments were requested a group ahead), the lo B fragments are
+    // requested at the head of the group and consumed by the hi*lo MFMAs, the lo*hi ones close the group
+    auto gemm8 = [&](lds_p wbase, const bf16x8 (&wlo)[KC], lds_p eb, f32x4 (&d)[2][NST]) {
+        constexpr int NG = 2 * KC;
+        bf16x8 w[2], xh[2][NST], xl[NST];
+        auto fetch_hi = [&](int j, bf16x8 (&xx)[NST]) {
+            const int kc = j >> 1, ps = j & 1;
+            if (ps == 0) w[kc & 1] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(wbase + kc * 1024);
+#pragma unroll
+            for (int s = 0; s < NST; s++) xx[s] = bfrag(eb + ps * EB, kc, s);
+        };
+        fetch_hi(0, xh[0]);
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            const int kc = j >> 1, ps = j & 1;
+#pragma unroll
+            for (int s = 0; s < NST; s++) xl[s] = bfrag(eb + ps * EB + EB1, kc, s);
+            if (j + 1 < NG) fetch_hi(j + 1, xh[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NST; s++) d[ps][s] = mfma(w[kc & 1], xh[j & 1][s], d[ps][s]);
+#pragma unroll
+            for (int s = 0; s < NST; s++) d[ps][s] = mfma(w[kc & 1], xl[s], d[ps][s]);
+#pragma unroll
+            for (int s = 0; s < NST; s++) d[ps][s] = mfma(wlo[kc], xh[j & 1][s], d[ps][s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    PointRec nxt = load_rec(0);
+    for (int64_t itx = 0; itx < iters; itx++) {
+        const int64_t tile = itx * tstride + (int64_t)blockIdx.x * C::GROUPS + grp;
+        const int64_t idx = tile * 16 + c;
+        const bool valid = tile < ntile && idx < A.n;
+        const PointRec cur = nxt;
+        if (itx + 1 < iters) nxt = load_rec(itx + 1);
+        // ================= P1: inputs and layer 0 of both passes =================
+        float inA[2][NST], ri1, ri2;
+        {
+            const float rho2 = cur.y * cur.y + cur.z * cur.z, rho = __builtin_amdgcn_sqrtf(rho2);
+            orbital_cyl<float>(cur.x - cur.R, rho2, rho, inA[0], ri1);
+            orbital_cyl<float>(cur.x + cur.R, rho2, rho, inA[1], ri2);
+        }
+        const float F = inA[0][0] + A.P * inA[1][0];
+        const float lapF = inA[0][SLP] + A.P * inA[1][SLP];
+        f32x4 h0[2], sv[2][NST];
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++) {
+            f32x4 a[NST];
+#pragma unroll
+            for (int s = 0; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
+            a[0] += b0;
+            f32x4 s0, s1, s2;
+            act012v<ACT>(a[0], s0, s1, s2);
+            const f32x4 q = a[1] * a[1] + a[2] * a[2];
+            h0[ps] = s0;
+            put(XB + ps * EB, 0, s0);
+            put(XB + ps * EB, 1, s1 * a[1]);
+            put(XB + ps * EB, 2, s1 * a[2]);
+            put(XB + ps * EB, SLP, s1 * a[SLP] + s2 * q);
+        }
+        __syncthreads();
+        // ================= P2: layer-1 GEMM over both passes, activations, output partial sums =================
+        {
+            f32x4 acc[2][NST];
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) {
+                acc[ps][0] = b1;
+#pragma unroll
+                for (int s = 1; s < NST; s++) acc[ps][s] = splat(0.f);
+            }
+            gemm8(wfwd, wlo_f, XB, acc);
+            float Sv = 0.f, Sl = 0.f;
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) {
+                f32x4 s0, s1, s2;
+                act012v<ACT>(acc[ps][0], s0, s1, s2);
+                const f32x4 q = acc[ps][1] * acc[ps][1] + acc[ps][2] * acc[ps][2];
+                const f32x4 ol = s1 * acc[ps][SLP] + s2 * q;
+                sv[ps][0] = s0;
+#pragma unroll
+                for (int s = 1; s < NST; s++) sv[ps][s] = acc[ps][s];
+                const float pw = ps ? A.P : 1.0f;
+                Sv += pw * dot4(wo, s0);
+                Sl += pw * dot4(wo, ol);
+            }
+            const float tot = xg_sum_pair(Sv, Sl);
+            if ((g & 1) == 0) SB[(part * 16 + c) * 2 + (g >> 1)] = tot;
+        }
+        __syncthreads();
+        // ================= P3: tail, last hidden layer's adjoints of both passes =================
+        Tail<float> t;
+        {
+            float Sv = 0.f, Sl = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < C::WPG; pp++) { Sv += SB[(pp * 16 + c) * 2]; Sl += SB[(pp * 16 + c) * 2 + 1]; }
+            tail<float>(A.out_scale * Sv + bout, A.out_scale * Sl, cur.g, cur.E, F, lapF, ri1 + ri2, A.a, A.b, A.c,
+                        float(cur.mk & 1), float((cur.mk >> 1) & 1), A.invN, invN1, invN2, valid ? 1.0f : 0.0f, t);
+            if (valid && g == 0 && part == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+            acc_pde += lead * t.l_pde;
+            acc_bc1 += lead * t.l_bc1;
+            acc_bc2 += lead * t.l_bc2;
+            acc_bout += lead * t.Nb;
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++) {
+            const float pw = ps ? A.P : 1.0f;
+            const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
+            const f32x4 h = sv[ps][0];
+            f32x4 s1, s2, s3;
+            act123v<ACT>(h, s1, s2, s3);
+            const f32x4 q = sv[ps][1] * sv[ps][1] + sv[ps][2] * sv[ps][2];
+            woacc += cv * h + cl * (s1 * sv[ps][SLP] + s2 * q);
+            const f32x4 o0 = cv * wo, ol = cl * wo;
+            const f32x4 u = 2.0f * s2 * ol;
+            const f32x4 y0 = s1 * o0 + (s2 * sv[ps][SLP] + s3 * q) * ol;
+            bacc1 += y0;
+            put(YB + ps * EB, 0, y0);
+            put(YB + ps * EB, 1, u * sv[ps][1]);
+            put(YB + ps * EB, 2, u * sv[ps][2]);
+            put(YB + ps * EB, SLP, s1 * ol);
+        }
+        __syncthreads();
+        // ================= P4: weight gradient, input-adjoint GEMM, layer-0 adjoints =================
+        {   // K = 128 columns = 4 steps (pass, stream pair); three MFMAs per (step, column tile)
+            bf16x8 fyh, fyl, fxh[2][HT], fxl[HT];
+            auto fetch_hi = [&](int k, bf16x8 (&x)[HT]) {
+#pragma unroll
+                for (int it = 0; it < HT; it++) x[it] = trfrag(XB + (k >> 1) * EB, it, k & 1);
+            };
+            fetch_hi(0, fxh[0]);
+#pragma unroll
+            for (int k = 0; k < NST; k++) {
+                fyh = trfrag(YB + (k >> 1) * EB, part, k & 1);
+                fyl = trfrag(YB + (k >> 1) * EB + EB1, part, k & 1);
+#pragma unroll
+                for (int it = 0; it < HT; it++) fxl[it] = trfrag(XB + (k >> 1) * EB + EB1, it, k & 1);
+                if (k + 1 < NST) fetch_hi(k + 1, fxh[(k + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < HT; it++) wacc[it] = mfma(fyh, fxh[k & 1][it], wacc[it]);
+#pragma unroll
+                for (int it = 0; it < HT; it++) wacc[it] = mfma(fyh, fxl[it], wacc[it]);
+#pragma unroll
+                for (int it = 0; it < HT; it++) wacc[it] = mfma(fyl, fxh[k & 1][it], wacc[it]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+            f32x4 ob[2][NST];
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++)
+#pragma unroll
+                for (int s = 0; s < NST; s++) ob[ps][s] = splat(0.f);
+            gemm8(wbwd, wlo_b, YB, ob);
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) {
+                f32x4 a[NST];
+#pragma unroll
+                for (int s = 1; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
+                f32x4 s1, s2, s3;
+                act123v<ACT>(h0[ps], s1, s2, s3);
+                const f32x4 q = a[1] * a[1] + a[2] * a[2];
+                const f32x4 u = 2.0f * s2 * ob[ps][SLP];
+                f32x4 ab[NST];
+                ab[SLP] = s1 * ob[ps][SLP];
+                ab[1] = s1 * ob[ps][1] + u * a[1];
+                ab[2] = s1 * ob[ps][2] + u * a[2];
+                ab[0] = s1 * ob[ps][0] + s2 * (a[1] * ob[ps][1] + a[2] * ob[ps][2]) + (s2 * a[SLP] + s3 * q) * ob[ps][SLP];
+                bacc0 += ab[0];
+#pragma unroll
+                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * inA[ps][s]; w0acc1 += ab[s] * inA[1 - ps][s]; }
+            }
+        }
+        __syncthreads();   // one set of exchange buffers: P1 of the next tile overwrites XB
+    }
+    // =========================== block reduction ===========================
+    constexpr int PT = Lay::size;
+    float* out = A.partial + (size_t)blockIdx.x * A.stride;
+    const float s0 = row16_sum(xg_sum(acc_pde)), s1r = row16_sum(xg_sum(acc_bc1)),
+                s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        bacc0[r] = row16_sum(bacc0[r]); bacc1[r] = row16_sum(bacc1[r]);
+        w0acc0[r] = row16_sum(w0acc0[r]); w0acc1[r] = row16_sum(w0acc1[r]);
+        woacc[r] = row16_sum(woacc[r]);
+    }
+    // group 1 hands its accumulators to group 0 through LDS (the exchange buffers are dead): [wave][36][64 lanes]
+    float* xfer = reinterpret_cast<float*>(lds_raw + C::OFF_G) + (size_t)part * 36 * 64 + lane;
+    float* sc = reinterpret_cast<float*>(lds_raw);
+    if (threadIdx.x < 4) sc[threadIdx.x] = 0.f;
+    if (grp == 1) {
+#pragma unroll
+        for (int it = 0; it < HT; it++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) xfer[(it * 4 + r) * 64] = wacc[it][r];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            xfer[(16 + r) * 64] = bacc0[r]; xfer[(20 + r) * 64] = bacc1[r]; xfer[(24 + r) * 64] = w0acc0[r];
+            xfer[(28 + r) * 64] = w0acc1[r]; xfer[(32 + r) * 64] = woacc[r];
+        }
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int it = 0; it < HT; it++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nj = q_neuron(16 * part + 4 * g + r), ni = q_neuron(16 * it + c);
+                out[Lay::W(1) + nj * H + ni] = wacc[it][r] + xfer[(it * 4 + r) * 64];
+            }
+        if (c == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nj = n0 + r;
+                out[Lay::b(0) + nj] = bacc0[r] + xfer[(16 + r) * 64];
+                out[Lay::b(1) + nj] = bacc1[r] + xfer[(20 + r) * 64];
+                out[Lay::W(0) + 2 * nj] = w0acc0[r] + xfer[(24 + r) * 64];
+                out[Lay::W(0) + 2 * nj + 1] = w0acc1[r] + xfer[(28 + r) * 64];
+                out[Lay::Wout + nj] = woacc[r] + xfer[(32 + r) * 64];
+            }
+        }
+    }
+    for (int w = 0; w < C::WAVES; w++) {   // per-point sums live in one wave per group; fixed order
+        if (wave == w && lane == 0) { sc[0] += s0; sc[1] += s1r; sc[2] += s2r; sc[3] += s3r; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
+    if (threadIdx.x == 3) out[Lay::bout] = sc[3];
+}
+
+template <int ACT>
+hipError_t launch_trunk2x_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
+{
+    using C1 = MCfg<64, 2>;
+    using C = T2xCfg;
+    const int nfrag = C1::NW * 2 * C1::HT * C1::KC * 64;
+    hipLaunchKernelGGL((k_pack_weights<64, 2, true>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    auto kern = k_trunk2x<ACT>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::WAVES * 64), C::LDS_BYTES, st, theta, (const __bf16*)wpk, A);
+    return hipGetLastError();
+}
+
+// =====================================================================================
 // R-only nets (E-net 1 -> 32 -> 32 -> 1, gate 1 -> 10 -> 1) in the trunk's transposed layout:
 // a wave owns 16 points; lane (g, c) holds, for point c, neurons 16 jt + 4 g + r of both row
 // tiles.  The 32 x 32 layer (forward, its transpose in the reverse sweep) is three split-bf16
@@ -2227,7 +2604,13 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
     //   2x64 : <4,4> x 2 blocks/CU 0.72 (<4,8> 0.74, <2,8> spills)     2x128: <8,8> 1.88 (<4,4> 2.7)
     //   4x64 : <2,4> 2.27 (<4,8> 4.2)                                   4x128: <4,4> 11.8 (<8,8> 15.4)
     // (round 2, four streams: 2x64 0.57, 3 blocks/CU 0.69, <4,8> 0.58; 4x128 <4,4> 7.6, <8,8> 8.3)
-    if (x3) {   // split-bf16 operands (3 MFMAs per product): neuron-split kernel only
+    if (x3) {   // split-bf16 operands (3 MFMAs per product)
+        if (H == 64 && L == 2 && npass == 2 && mode == MODE_BWD && mfma_variant() != 3) {
+            // the benchmark's shape in fp32-grade mode: both passes swept together (k_trunk2x)
+            *err = act == ACT_TANH ? launch_trunk2x_t<ACT_TANH>(theta, wpk, A, grid, st)
+                                   : launch_trunk2x_t<ACT_SIGMOID>(theta, wpk, A, grid, st);
+            return true;
+        }
         if (H == 64 && L == 2) {
             return launch2_HL<64, 2, 4, 8, true>(act, npass, mode, theta, wpk, A, grid, st, err);
         }

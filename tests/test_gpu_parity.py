@@ -565,6 +565,39 @@ def test_benchmarked_instance_at_full_size_shards_add_up_and_match_oracle():
     assert rel(first[:P].double().cpu().numpy(), ref["grad"]) < 3e-2
 
 
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("n", [1, 17, 255, 257, 4113])
+def test_merged_pass_kernels_ragged_sizes(n, prec):
+    """k_trunk2 (point-record ring, tile groups) and k_trunk2x at sizes that leave tiles, ring batches and
+    tile groups partly empty: loss and gradient against the oracle at the path's tolerance, and the same
+    numbers from the per-pass kernel (PINN_MFMA_VARIANT=3) to fp32 round-off"""
+    A = O.arch(H=64, act=1)
+    rng = np.random.default_rng(77 + n)
+    off, sz = O.tensor_layout(A)
+    theta = np.zeros(O.param_count(A))
+    fan = [2, 2, 64, 64, 64, 64, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    for o, s_, fi in zip(off, sz, fan):
+        theta[o:o + s_] = rng.uniform(-1, 1, s_) / np.sqrt(fi)
+    x, y, z = rng.uniform(-18, 18, (3, n))
+    R = rng.uniform(0.2, 4, n)
+    mask = rng.integers(0, 4, n).astype(np.uint8)
+    f = pkg.model.FORMULATION_A
+    pr = capi.PINN_PREC_BF16 if prec == "bf16" else capi.PINN_PREC_BF16X3
+    h = capi.Handle(capi.Arch(64, 2, 32, 10, 1, 2, 1.0, pr), 0, 8192)
+    ref = O.loss_grad(A, O.ham_A(), theta, x, y, z, R, mask)
+    try:
+        os.environ["PINN_MFMA_VARIANT"] = "0"
+        out = run_loss_grad(h, f, theta, x, y, z, R, mask)
+        os.environ["PINN_MFMA_VARIANT"] = "3"
+        old = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    finally:
+        os.environ.pop("PINN_MFMA_VARIANT", None)
+    P = h.P
+    tol = 5e-2 if prec == "bf16" else 2e-4
+    assert abs(out[P:].sum() / ref["Ltot"] - 1) < tol and rel(out[:P], ref["grad"]) < tol
+    assert abs(out[P:].sum() / old[P:].sum() - 1) < 2e-5 and rel(out[:P], old[:P]) < 2e-5
+
+
 @pytest.mark.parametrize("H,L,form,act", [(64, 2, "B", 1), (128, 2, "A", 0), (128, 2, "B", 1),
                                            (64, 4, "A", 1), (128, 4, "A", 1), (128, 4, "B", 0)])
 def test_mfma_bf16_matches_oracle(H, L, form, act):

@@ -121,10 +121,19 @@ ARCHS["wide4x128x3"] = dict(ARCHS["wide4x128"], precision="bf16x3", dtype="bf16x
 # HBM bytes per launch of each workload's trunk kernel from this round's rocprofv3 PMC passes (FETCH_SIZE x 2 --
 # the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r02_default_bench.md).  The 4x128
 # split-bf16 kernel still spills (560 B/lane): most of its traffic is scratch.
-TRAFFIC = {"wide64": 71.7e6, "wide64x3": 40.1e6, "ref16": 41.3e6, "ref16ft": 34.7e6, "wide128": 80.3e6,
-           "wide4x128x3": 2280e6}
+TRAFFIC = {"wide64": 71.7e6, "wide64x3": 44.2e6, "ref16": 34.1e6, "ref16ft": 34.7e6, "wide128": 85.3e6,
+           "wide4x128x3": 2231e6}
 TRAFFIC_SOURCE = "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r02_default_bench.md"
 DEFAULT_ARCH = "wide64"
+
+
+def _mfma_kernel_name(arch):
+    """the trunk kernel launch_trunk_mfma dispatches this workload to (csrc/pinn_trunk_mfma.hip)"""
+    if arch["L"] == 2 and arch.get("n_pass", 2) == 2:
+        if arch.get("precision") == "bf16x3":
+            return "k_trunk2x" if arch["H"] == 64 else "k_trunk_mfma2"
+        return "k_trunk2"
+    return "k_trunk_mfma2"
 SECONDARY = {"wide64": ["wide64x3", "wide4x128x3", "ref16", "ref16ft", "wide128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
              "wide128": ["wide128x3"], "wide128x3": ["wide128"]}
 # tolerances the GPU parity tests hold each path to, against the fp64 oracle / reference vectors
@@ -404,7 +413,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": TRAFFIC.get(args.arch),
                          "traffic_source": TRAFFIC_SOURCE,
-                         "kernel": ("k_trunk16" if arch["H"] == 16 else "k_trunk") if arch["dtype"] == "f32" else "k_trunk_mfma2",
+                         "kernel": ("k_trunk16" if arch["H"] == 16 else "k_trunk") if arch["dtype"] == "f32" else _mfma_kernel_name(arch),
                          "kernel_ms": trunk_ms, "flops_per_point": fl_trunk,
                          "note": ("fp32-grade path: algorithmic flops against the fp32 vector peak (157.3 TFLOP/s); the layer GEMMs "
                                   "run as split-bf16 MFMAs, the kernel is bound by its fp32 elementwise algebra"

@@ -27,6 +27,7 @@ struct TrunkArgs {
 size_t mfma_packed_weight_bytes(int H, int L);
 bool mfma_trunk_supported(int H, int L);
 int mfma_partial_stride(int H, int L);
+size_t mfma_stash_bytes(int H, int L, bool x3, int nblocks);   // k_trunkD's parked state, behind the packed weights
 int mfma_blocks_per_cu(int H, int L, bool x3);   // resident blocks per CU of the chosen kernel   // floats per block partial row (trunk grads + 3)
 // enqueue pack + trunk kernel; returns false when (H, L, act, npass, mode) has no instantiation
 bool mfma_x3_supported(int H, int L);

@@ -1266,7 +1266,8 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     HIPCHK(h, hipMalloc(&h->tensor_of, h->P));
     HIPCHK(h, hipMalloc(&h->thT, sizeof(float) * h->P));
     if (arch->precision != PINN_PREC_F32)
-        HIPCHK(h, hipMalloc(&h->wpk, mfma_packed_weight_bytes(arch->H, arch->L)));
+        HIPCHK(h, hipMalloc(&h->wpk, mfma_packed_weight_bytes(arch->H, arch->L) +
+                                         mfma_stash_bytes(arch->H, arch->L, arch->precision == PINN_PREC_BF16X3, h->nbT)));
     {
         int64_t off[64], sz[64];
         pinn_tensor_layout(arch, off, sz);

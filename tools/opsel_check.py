@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""List packed-fp32 VALU instructions whose LOW result lane reads the HIGH dword of an operand pair
+(v_pk_{mul,fma,add}_f32 ... op_sel:[..1..]) per kernel of csrc/pinn_trunk_mfma.hip.
+
+    python tools/opsel_check.py [substring ...]
+
+Why: on MI355X these forms gave run-to-run different products in k_trunk2 when two workgroups shared a CU
+(profiles/r02_packed_opsel.md); the ring-fed arithmetic of the merged-pass kernels is written so that none is
+emitted there (lin2 / fmac_bcast in the source).  The tool compiles the translation unit to assembly (~40 s)."""
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pinn_for_quantum_wavefunction_surfaces_amd", "csrc")
+
+
+def scan(asm_path):
+    cur, hits, tot = None, collections.defaultdict(list), collections.Counter()
+    for line in open(asm_path):
+        m = re.match(r"^(_Z\S+):", line)
+        if m:
+            cur = m.group(1)
+        if cur and re.search(r"\tv_pk_(mul|fma|add)_f32", line):
+            tot[cur] += 1
+            if re.search(r"op_sel:\[", line):
+                hits[cur].append(line.strip())
+    return hits, tot
+
+
+def main():
+    filt = sys.argv[1:]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "t.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value",
+                               "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out,
+                               os.path.join(CSRC, "pinn_trunk_mfma.hip")], stderr=subprocess.DEVNULL)
+        hits, tot = scan(out)
+    names = subprocess.run(["c++filt"], input="\n".join(tot), capture_output=True, text=True).stdout.splitlines()
+    for k, n in zip(tot, names):
+        if filt and not all(f in k or f in n for f in filt):
+            continue
+        print("%3d of %4d packed ops  %s" % (len(hits[k]), tot[k], k if n.startswith("_Z") else n[:100]))
+        for h in hits[k]:
+            print("        " + h)
+
+
+if __name__ == "__main__":
+    main()

@@ -10,10 +10,16 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libpinn_hip.so")
-# per-source extra flags.  pinn_kernels.hip: -fno-slp-vectorize, because the SLP pass packs
-# scalar FMAs into v_pk_* and then has to copy the SGPR-resident weights into VGPR pairs
-# first (+40 % VALU instructions).  The MFMA trunk keeps SLP (its operands are VGPR vectors).
-SOURCES = {"pinn_kernels.hip": ["-fno-slp-vectorize"], "pinn_trunk_mfma.hip": [], "pinn_xchg.hip": []}
+# translation units: (object name, source, extra flags).  pinn_kernels.hip: -fno-slp-vectorize, because the SLP
+# pass packs scalar FMAs into v_pk_* and then has to copy the SGPR-resident weights into VGPR pairs first (+40 %
+# VALU instructions).  pinn_trunk_mfma.hip is compiled twice: part 0 (everything but the 4x128 kernels) keeps SLP
+# (2-4 % faster 2-layer kernels), part 1 (the 4x128 kernels) drops it (fewer spills at that register pressure:
+# 4-19 % faster).
+UNITS = [("pinn_kernels.o", "pinn_kernels.hip", ["-fno-slp-vectorize"]),
+         ("pinn_trunk_mfma.o", "pinn_trunk_mfma.hip", []),
+         ("pinn_trunk_mfma_p1.o", "pinn_trunk_mfma.hip", ["-DPINN_TRUNK_PART=1", "-fno-slp-vectorize"]),
+         ("pinn_xchg.o", "pinn_xchg.hip", [])]
+SOURCES = sorted({u[1] for u in UNITS})
 HEADERS = ["pinn_math.h", "pinn_common.h", os.path.join("..", "..", "include", "pinn.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
@@ -36,8 +42,8 @@ def build_hip(force=False, verbose=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []
-    for src, extra in SOURCES.items():
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+    for objname, src, extra in UNITS:
+        obj = os.path.join(objdir, objname)
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(
                 os.path.getmtime(os.path.join(CSRC, d)) for d in [src] + HEADERS):

@@ -31,6 +31,9 @@ size_t mfma_stash_bytes(int H, int L, bool x3, int nblocks);   // k_trunkD's par
 int mfma_blocks_per_cu(int H, int L, bool x3);   // resident blocks per CU of the chosen kernel   // floats per block partial row (trunk grads + 3)
 // enqueue pack + trunk kernel; returns false when (H, L, act, npass, mode) has no instantiation
 bool mfma_x3_supported(int H, int L);
+// the 4x128 shapes live in a second translation unit of pinn_trunk_mfma.hip (built without SLP vectorization)
+bool launch_trunk_mfma_128x4(int act, int npass, int mode, bool x3, int variant, const float* theta, void* packed_weights,
+                             const TrunkArgs& A, int grid, hipStream_t st, hipError_t* err);
 bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, const float* theta,
                        void* packed_weights, const TrunkArgs& A, int grid, hipStream_t st,
                        hipError_t* err);

@@ -45,6 +45,10 @@
 #include "pinn_math.h"
 #include "pinn_common.h"
 
+#ifndef PINN_TRUNK_PART
+#define PINN_TRUNK_PART 0
+#endif
+
 using namespace pinn;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -3032,6 +3036,8 @@ hipError_t launch_trunk16_t(int mode, const float* theta, const TrunkArgs& A, in
 
 }  // namespace
 
+#if PINN_TRUNK_PART == 0
+
 // ---- R-only nets on the matrix pipe (see k_rnet_mfma_fwd / k_rnet_mfma_bwd)
 bool rnet_mfma_supported(int HE, int HG)
 {
@@ -3119,6 +3125,8 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
                        hipError_t* err)
 {
     __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
+    if (H == 128 && L == 4)   // compiled in the second translation unit of this file (PINN_TRUNK_PART == 1)
+        return launch_trunk_mfma_128x4(act, npass, mode, x3, mfma_variant(), theta, packed_weights, A, grid, st, err);
     // <H, L, SPLIT, WAVES, X3, OCC>: SPLIT waves share a 16-point tile, WAVES per block, OCC resident
     // blocks per CU.  One decomposition per shape, the fastest measured (round 1, 1M points, kernel ms):
     //   2x64 : <4,4> x 2 blocks/CU 0.72 (<4,8> 0.74, <2,8> spills)     2x128: <8,8> 1.88 (<4,4> 2.7)
@@ -3140,9 +3148,6 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
             // hi weight plane in LDS (64 KB), lo plane from L2, one pass resident: 4.3 ms
             return launch2_HL<128, 2, 8, 8, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         }
-        if (H == 128 && L == 4)   // BASELINE config 1 (4x128 fp32-grade): hi plane streamed through LDS by
-                                  // LDS-DMA, lo plane from L2, one layer-output buffer (XONE)
-            return launch2_HL<128, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         return false;
     }
     if (L == 2 && npass == 2 && mode == MODE_BWD && mfma_variant() != 3 && (H == 64 || H == 128)) {
@@ -3153,17 +3158,36 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
                                     : launch_trunk2_t<128, ACT_SIGMOID>(theta, wpk, A, grid, st);
         return true;
     }
-    if (L == 4 && npass == 2 && mode == MODE_BWD && mfma_variant() != 3 && (H == 64 || H == 128)) {
+    if (L == 4 && npass == 2 && mode == MODE_BWD && mfma_variant() != 3 && H == 64) {
         // deep trunks: both passes swept together, weights from L2 into registers (k_trunkD)
-        if (H == 64) *err = act == ACT_TANH ? launch_trunkD_t<64, 4, ACT_TANH>(theta, wpk, A, grid, st)
-                                            : launch_trunkD_t<64, 4, ACT_SIGMOID>(theta, wpk, A, grid, st);
-        else *err = act == ACT_TANH ? launch_trunkD_t<128, 4, ACT_TANH>(theta, wpk, A, grid, st)
-                                    : launch_trunkD_t<128, 4, ACT_SIGMOID>(theta, wpk, A, grid, st);
+        *err = act == ACT_TANH ? launch_trunkD_t<64, 4, ACT_TANH>(theta, wpk, A, grid, st)
+                               : launch_trunkD_t<64, 4, ACT_SIGMOID>(theta, wpk, A, grid, st);
         return true;
     }
     if (H == 64 && L == 2) return launch2_HL<64, 2, 4, 4, false, 2>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (H == 128 && L == 2) return launch2_HL<128, 2, 8, 8>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (H == 64 && L == 4) return launch2_HL<64, 4, 2, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
-    if (H == 128 && L == 4) return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
     return false;
 }
+
+#else   // ---- PINN_TRUNK_PART == 1: the 4x128 kernels, built WITHOUT the SLP vectorizer
+// This file is compiled twice (build.py).  The second pass defines only this launcher and instantiates only
+// the 4x128 kernels, with -fno-slp-vectorize: at that register pressure the SLP pass costs more in spills
+// than its packed instructions save (k_trunkD<128> 3.94 -> 3.78 ms per 1M points, 432 -> 96 B of scratch; the
+// split-bf16 kernel of BASELINE config 1 1.80 -> 1.46 ms per 100 000 points), while the 2-layer kernels are
+// 2-4 % faster with it.
+bool launch_trunk_mfma_128x4(int act, int npass, int mode, bool x3, int variant, const float* theta, void* packed_weights,
+                             const TrunkArgs& A, int grid, hipStream_t st, hipError_t* err)
+{
+    __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
+    if (x3)   // BASELINE config 1 (4x128 fp32-grade): hi plane streamed through LDS by LDS-DMA, lo plane from
+              // L2, one layer-output buffer (XONE)
+        return launch2_HL<128, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
+    if (npass == 2 && mode == MODE_BWD && variant != 3) {
+        *err = act == ACT_TANH ? launch_trunkD_t<128, 4, ACT_TANH>(theta, wpk, A, grid, st)
+                               : launch_trunkD_t<128, 4, ACT_SIGMOID>(theta, wpk, A, grid, st);
+        return true;
+    }
+    return launch2_HL<128, 4, 4, 4>(act, npass, mode, theta, wpk, A, grid, st, err);
+}
+#endif

@@ -17,13 +17,13 @@ SO = os.path.join(PKG, "libpinn_hip_stamps.so")
 
 
 def build():
-    srcs = ["pinn_kernels.hip", "pinn_trunk_mfma.hip", "pinn_xchg.hip"]
+    sys.path.insert(0, ROOT)
+    from pinn_for_quantum_wavefunction_surfaces_amd.build import UNITS
     objs = []
-    for s in srcs:
-        o = os.path.join(PKG, "build", s.replace(".hip", ".stamps.o"))
-        extra = ["-fno-slp-vectorize"] if s == "pinn_kernels.hip" else []
+    for objname, src, extra in UNITS:
+        o = os.path.join(PKG, "build", objname.replace(".o", ".stamps.o"))
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
-                               "-Wno-unused-value", "-DPINN_STAMPS"] + extra + ["-c", "-o", o, s],
+                               "-Wno-unused-value", "-DPINN_STAMPS"] + extra + ["-c", "-o", o, src],
                               cwd=os.path.join(PKG, "csrc"))
         objs.append(o)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)

@@ -119,22 +119,26 @@ ARCHS["wide4x128x3"] = dict(ARCHS["wide4x128"], precision="bf16x3", dtype="bf16x
                                   "(split-bf16 MFMA trunk: hi+lo operands, 3 MFMAs per product, fp32 accumulate "
                                   "and elementwise), 100 000 points/step, seeded random init")
 # HBM bytes per launch of each workload's trunk kernel from this round's rocprofv3 PMC passes (FETCH_SIZE x 2 --
-# the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r02_default_bench.md).  The 4x128
-# split-bf16 kernel still spills (560 B/lane): most of its traffic is scratch.
-TRAFFIC = {"wide64": 71.7e6, "wide64x3": 44.2e6, "ref16": 34.1e6, "ref16ft": 34.7e6, "wide128": 85.3e6,
-           "wide4x128x3": 2231e6}
+# the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r02_default_bench.md).  4x128 bf16
+# (k_trunkD<128>): 7.3 GB, nearly all of it the saved layer state the kernel parks in global memory and reads back
+# (64 KB per tile and block, rewritten every tile); the 4x128 split-bf16 kernel still spills (most of its traffic).
+TRAFFIC = {"wide64": 71.7e6, "wide64x3": 44.2e6, "ref16": 34.1e6, "ref16ft": 34.7e6, "wide128": 80.3e6,
+           "wide4x128x3": 945e6, "wide4x64": 89.7e6, "wide4x128": 7330e6}
 TRAFFIC_SOURCE = "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r02_default_bench.md"
 DEFAULT_ARCH = "wide64"
 
 
 def _mfma_kernel_name(arch):
     """the trunk kernel launch_trunk_mfma dispatches this workload to (csrc/pinn_trunk_mfma.hip)"""
-    if arch["L"] == 2 and arch.get("n_pass", 2) == 2:
-        if arch.get("precision") == "bf16x3":
-            return "k_trunk2x" if arch["H"] == 64 else "k_trunk_mfma2"
-        return "k_trunk2"
+    if arch.get("n_pass", 2) == 2 and not arch.get("fine_tune", False):
+        if arch["L"] == 2:
+            if arch.get("precision") == "bf16x3":
+                return "k_trunk2x" if arch["H"] == 64 else "k_trunk_mfma2"
+            return "k_trunk2"
+        if arch["L"] == 4 and arch.get("precision") != "bf16x3":
+            return "k_trunkD"
     return "k_trunk_mfma2"
-SECONDARY = {"wide64": ["wide64x3", "wide4x128x3", "ref16", "ref16ft", "wide128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
+SECONDARY = {"wide64": ["wide64x3", "wide4x128x3", "ref16", "ref16ft", "wide128", "wide4x64", "wide4x128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
              "wide128": ["wide128x3"], "wide128x3": ["wide128"]}
 # tolerances the GPU parity tests hold each path to, against the fp64 oracle / reference vectors
 # (tests/test_gpu_parity.py).  What THIS run observed is measured in the cpu_baseline leg ("parity_observed").

@@ -487,6 +487,19 @@ struct Tail {
     T l_pde, l_bc1, l_bc2;  // this point's scaled loss contributions
 };
 
+// keeps hipcc's SLP vectorizer from pairing a value with its neighbour into one packed instruction (device, fp32
+// only; a no-op elsewhere).  Used where the pairing produces v_pk_mul_f32 ... op_sel:[0,1] -- see
+// profiles/r02_packed_opsel.md.
+template <class T>
+PINN_HD void slp_opaque(T& x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
+
 template <class T>
 PINN_HD void tail(T N, T lapN, T g, T E, T F, T lapF, T U, T a, T b, T c, T m1, T m2, T invN,
                   T invN1, T invN2, T live, Tail<T>& t)
@@ -494,6 +507,7 @@ PINN_HD void tail(T N, T lapN, T g, T E, T F, T lapF, T U, T a, T b, T c, T m1, 
     t.psi = g * N + F;
     t.lap = g * lapN + lapF;
     T Vc = b * U + c * E;
+    slp_opaque(Vc);
     t.res = a * t.lap + Vc * t.psi;
     T resb = T(2) * t.res * invN * live;
     T bcw = (m1 * invN1 + m2 * invN2) * live;

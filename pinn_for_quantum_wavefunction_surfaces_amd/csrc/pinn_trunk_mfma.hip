@@ -202,6 +202,11 @@ __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(b
 // workgroup shared the CU (two waves of different workgroups per SIMD): identical operands, results differing
 // from run to run in the d/dx stream (tools/dbg notes in profiles/r02_packed_opsel.md).  The scalar forms cost
 // ~45 issue cycles per tile and wave (1.5 %) and are bitwise reproducible.
+// hipcc's hazard recognizer does not look into inline assembly: the operands of these helpers must not be results
+// of MFMA instructions (the callers pass weights, point-record values and results of ordinary VALU arithmetic), and
+// only the _t variants (one asm block, opened by a wait state) may be given the result of a transcendental
+// instruction, which a VALU instruction may read one wait state later at the earliest on gfx940+ -- the orbital
+// values computed inline in k_trunk16 are such results; the ring-fed kernels read theirs from LDS.
 __device__ __forceinline__ f32x4 lin2(f32x4 w0, float x0, f32x4 w1, float x1)   // w0 * x0 + w1 * x1
 {
     f32x4 r;
@@ -218,6 +223,27 @@ __device__ __forceinline__ void fmac_bcast(f32x4& acc, f32x4 v, float x)        
 {
 #pragma unroll
     for (int k = 0; k < 4; k++) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[k]) : "v"(v[k]), "v"(x));
+}
+
+__device__ __forceinline__ f32x4 lin2_t(f32x4 w0, float x0, f32x4 w1, float x1)
+{
+    float r0, r1, r2, r3;
+    asm("s_nop 0\n\t"
+        "v_mul_f32 %0, %8, %13\n\tv_mul_f32 %1, %9, %13\n\tv_mul_f32 %2, %10, %13\n\tv_mul_f32 %3, %11, %13\n\t"
+        "v_fmac_f32 %0, %4, %12\n\tv_fmac_f32 %1, %5, %12\n\tv_fmac_f32 %2, %6, %12\n\tv_fmac_f32 %3, %7, %12"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(x0), "v"(x1));
+    return f32x4{r0, r1, r2, r3};
+}
+
+__device__ __forceinline__ void fmac_bcast_t(f32x4& acc, f32x4 v, float x)
+{
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    asm("s_nop 0\n\t"
+        "v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(x));
+    acc = f32x4{a0, a1, a2, a3};
 }
 
 __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c)
@@ -2034,39 +2060,45 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     // and elementwise temporaries live at a time; MFMA and VALU work do not overlap on a SIMD anyway), sharing
     // the A fragments and the phase's barriers.
     auto gemmP = [&](const bf16x8 (&a)[KC], lds_p eb, f32x4 (&d)[NST]) {
-        bf16x8 x[2][NST];
-        auto fetch = [&](int kc, bf16x8 (&xx)[NST]) {
+        constexpr int HS = NST;                     // streams per operand group
+        constexpr int NG = KC * (NST / HS);
+        bf16x8 x[2][HS];
+        auto fetch = [&](int j, bf16x8 (&xx)[HS]) {
+            const int kc = j / (NST / HS), s0 = (j % (NST / HS)) * HS;
 #pragma unroll
-            for (int s = 0; s < NST; s++) xx[s] = bfrag(eb, kc, s);
+            for (int s = 0; s < HS; s++) xx[s] = bfrag(eb, kc, s0 + s);
         };
         fetch(0, x[0]);
 #pragma unroll
-        for (int kc = 0; kc < KC; kc++) {
-            if (kc + 1 < KC) fetch(kc + 1, x[(kc + 1) & 1]);
+        for (int j = 0; j < NG; j++) {
+            if (j + 1 < NG) fetch(j + 1, x[(j + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+            const int kc = j / (NST / HS), s0 = (j % (NST / HS)) * HS;
 #pragma unroll
-            for (int s = 0; s < NST; s++) d[s] = mfma(a[kc], x[kc & 1][s], d[s]);
+            for (int s = 0; s < HS; s++) d[s0 + s] = mfma(a[kc], x[j & 1][s], d[s0 + s]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // weight gradient of one layer: K = 128 columns = NST steps (pass, stream pair) x HT column tiles
+    // weight gradient of one layer: K = 128 columns = NST steps (pass, stream pair) x HT column tiles, in groups
+    // of WG MFMAs whose operands are requested one group ahead
     auto wgrad = [&](f32x4 (&wa)[HT], lds_p yb, lds_p xb) {
-        constexpr int GPK = HT / 4, NG = NST * GPK;
-        bf16x8 fy[2], fx[2][4];
-        auto fetch = [&](int j, bf16x8 (&x)[4]) {
-            const int k = j / GPK, i0 = (j % GPK) * 4;
+        constexpr int WG = 4;
+        constexpr int GPK = HT / WG, NG = NST * GPK;
+        bf16x8 fy[2], fx[2][WG];
+        auto fetch = [&](int j, bf16x8 (&x)[WG]) {
+            const int k = j / GPK, i0 = (j % GPK) * WG;
             if (j % GPK == 0) fy[k & 1] = trfrag(yb + (k >> 1) * EB, part, k & 1);
 #pragma unroll
-            for (int i = 0; i < 4; i++) x[i] = trfrag(xb + (k >> 1) * EB, i0 + i, k & 1);
+            for (int i = 0; i < WG; i++) x[i] = trfrag(xb + (k >> 1) * EB, i0 + i, k & 1);
         };
         fetch(0, fx[0]);
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             if (j + 1 < NG) fetch(j + 1, fx[(j + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            const int k = j / GPK, i0 = (j % GPK) * 4;
+            const int k = j / GPK, i0 = (j % GPK) * WG;
 #pragma unroll
-            for (int i = 0; i < 4; i++) wa[i0 + i] = mfma(fy[k & 1], fx[j & 1][i], wa[i0 + i]);
+            for (int i = 0; i < WG; i++) wa[i0 + i] = mfma(fy[k & 1], fx[j & 1][i], wa[i0 + i]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -2078,7 +2110,10 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     };
 
     const lds_p YB = lds0 + C::OFF_Y;
-    PointRec nxt = load_rec(0);
+    // the raw points of a ring batch are requested a whole batch ahead (seven registers held for RB trips)
+    constexpr bool RPF = true;   // (false: load at the refill, 7 registers less, measured 1.5 % slower at 4x128)
+    PointRec nxt;
+    if (RPF) nxt = load_rec(0);
     bf16x8 afr[KC];
     loadA(0, afr);
     for (int64_t itx = 0; itx < iters; itx++) {
@@ -2088,8 +2123,12 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         const int slot = (int)(itx % RB);
         if (slot == 0) {
             if (itx) __syncthreads();           // the last reverse step of the previous trip read the old batch
-            fill_ring(nxt);
-            nxt = load_rec(itx / RB + 1);       // raw points of the next batch: nothing waits for them for RB trips
+            if (RPF) {
+                fill_ring(nxt);
+                nxt = load_rec(itx / RB + 1);   // raw points of the next batch: nothing waits for them for RB trips
+            } else {
+                fill_ring(load_rec(itx / RB));
+            }
             __syncthreads();
         }
         // ================= layer 0 of both passes -> X[0] =================
@@ -2834,7 +2873,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             }
             f32x4 a0[NST], ox[NST];
 #pragma unroll
-            for (int s = 0; s < NST; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
+            for (int s = 0; s < NST; s++) a0[s] = lin2_t(w0a, in[0][s], w0b, in[1][s]);
             a0[0] += T16_B0;
             {
                 f32x4 s0, s1, s2;
@@ -2954,7 +2993,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
             {
                 f32x4 a0[NST];
 #pragma unroll
-                for (int s = 1; s < NST; s++) a0[s] = w0a * in[0][s] + w0b * in[1][s];
+                for (int s = 1; s < NST; s++) a0[s] = lin2_t(w0a, in[0][s], w0b, in[1][s]);
                 const f32x4 h = h0s[ps];
                 f32x4 s1, s2, s3;
                 act123v<ACT>(h, s1, s2, s3);
@@ -2968,7 +3007,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
                         (s2 * a0[SLP] + s3 * q) * ob[SLP];
                 bacc0 += ab[0];
 #pragma unroll
-                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * in[0][s]; w0acc1 += ab[s] * in[1][s]; }
+                for (int s = 0; s < NST; s++) { fmac_bcast_t(w0acc0, ab[s], in[0][s]); fmac_bcast_t(w0acc1, ab[s], in[1][s]); }
             }
         }
     }

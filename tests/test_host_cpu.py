@@ -175,3 +175,21 @@ def test_torch_baseline_matches_oracle(golden_dir):
     Ltot.backward()
     assert abs(float(Ltot) / g["Ltot"] - 1) < 1e-12
     assert np.abs(th.grad.numpy() - g["grad"]).max() / np.abs(g["grad"]).max() < 1e-11
+
+
+def test_no_packed_opsel_forms_in_the_matrix_pipe_kernels():
+    """hipcc's v_pk_{mul,fma,add}_f32 ... op_sel:[..] (the LOW result lane reading the HIGH dword of an operand
+    pair) intermittently computed with 0 in place of that dword on MI355X (profiles/r02_packed_opsel.md,
+    tools/opselbench).  The sources of csrc/pinn_trunk_mfma.hip are written so that none is emitted (lin2,
+    fmac_bcast, slp_opaque); this compiles both translation units to assembly (no GPU needed) and looks."""
+    import shutil
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import opsel_check
+    hits, tot = opsel_check.compile_and_scan()
+    assert sum(tot.values()) > 10000          # the scan saw the kernels
+    bad = {k: v for k, v in hits.items() if v}
+    assert not bad, "packed op_sel forms in: %s" % sorted(bad)[:5]

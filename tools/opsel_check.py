@@ -31,22 +31,32 @@ def scan(asm_path):
     return hits, tot
 
 
-def main():
-    filt = sys.argv[1:]
+def compile_and_scan():
     sys.path.insert(0, ROOT)
     from pinn_for_quantum_wavefunction_surfaces_amd.build import UNITS
     hits, tot = collections.defaultdict(list), collections.Counter()
     with tempfile.TemporaryDirectory() as d:
+        procs = []
         for objname, src, extra in UNITS:
             if src != "pinn_trunk_mfma.hip":
                 continue
             out = os.path.join(d, objname + ".s")
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value"] + extra +
-                                  ["-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out,
-                                   os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
+            procs.append((out, subprocess.Popen(
+                ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value"] + extra +
+                ["-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)],
+                stderr=subprocess.DEVNULL)))
+        for out, pr in procs:
+            if pr.wait() != 0:
+                raise RuntimeError("hipcc failed")
             h, t = scan(out)
             hits.update(h)
             tot.update(t)
+    return hits, tot
+
+
+def main():
+    filt = sys.argv[1:]
+    hits, tot = compile_and_scan()
     names = subprocess.run(["c++filt"], input="\n".join(tot), capture_output=True, text=True).stdout.splitlines()
     for k, n in zip(tot, names):
         if filt and not all(f in k or f in n for f in filt):

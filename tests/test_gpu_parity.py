@@ -598,6 +598,41 @@ def test_merged_pass_kernels_ragged_sizes(n, prec):
     assert abs(out[P:].sum() / old[P:].sum() - 1) < 2e-5 and rel(out[:P], old[:P]) < 2e-5
 
 
+@pytest.mark.parametrize("H", [64, 128])
+@pytest.mark.parametrize("n", [1, 17, 4113, 300000])
+def test_deep_trunk_kernel_ragged_sizes_and_ring_refill(H, n):
+    """k_trunkD (4x64, 4x128 bf16) at sizes that leave tiles and ring batches partly empty, and at 300 000 points,
+    where every block refills its point-record ring (37 / 74 trips against ring batches of 16 / 32) and 4x128 parks
+    its layer state tile after tile: loss and gradient against the oracle at the bf16 tolerance (small sizes) and
+    against the pass-by-pass kernel (PINN_MFMA_VARIANT=3), which shares nothing with it but the weights' packing,
+    to well inside that tolerance."""
+    A = O.arch(H=H, L=4, act=1)
+    rng = np.random.default_rng(177 + n + H)
+    off, sz = O.tensor_layout(A)
+    theta = np.zeros(O.param_count(A))
+    fan = [2, 2] + [H, H] * 3 + [H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    for o, s_, fi in zip(off, sz, fan):
+        theta[o:o + s_] = rng.uniform(-1, 1, s_) / np.sqrt(fi)
+    x, y, z = rng.uniform(-18, 18, (3, n))
+    R = rng.uniform(0.2, 4, n)
+    mask = rng.integers(0, 4, n).astype(np.uint8)
+    f = pkg.model.FORMULATION_A
+    h = capi.Handle(capi.Arch(H, 4, 32, 10, 1, 2, 1.0, capi.PINN_PREC_BF16), 0, max(n, 8192))
+    try:
+        os.environ["PINN_MFMA_VARIANT"] = "0"
+        out = run_loss_grad(h, f, theta, x, y, z, R, mask)
+        os.environ["PINN_MFMA_VARIANT"] = "3"
+        old = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    finally:
+        os.environ.pop("PINN_MFMA_VARIANT", None)
+    P = h.P
+    assert np.isfinite(out).all()
+    assert abs(out[P:].sum() / old[P:].sum() - 1) < 1e-4 and rel(out[:P], old[:P]) < 8e-3
+    if n < 10000:
+        ref = O.loss_grad(A, O.ham_A(), theta, x, y, z, R, mask)
+        assert abs(out[P:].sum() / ref["Ltot"] - 1) < 5e-2 and rel(out[:P], ref["grad"]) < 5e-2
+
+
 @pytest.mark.parametrize("H,L,prec", [(16, 2, "f32"), (64, 2, "bf16"), (64, 2, "bf16x3"), (128, 2, "bf16"),
                                       (64, 4, "bf16"), (128, 4, "bf16")])
 def test_bitwise_reproducible_with_co_resident_blocks(H, L, prec):

@@ -195,18 +195,45 @@ __device__ __forceinline__ void act123v(f32x4 s, f32x4& s1, f32x4& s2, f32x4& s3
 
 __device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-// Vector-times-broadcast-scalar arithmetic on the values of the LDS point-record ring, on UNPACKED VALU
-// instructions.  Written as f32x4 expressions, hipcc broadcasts a scalar that sits in the odd register of a
-// pair with v_pk_mul_f32 / v_pk_fma_f32 ... op_sel:[0,1] (the LOW result lane reading the HIGH dword of the
-// operand pair).  On MI355X those instructions intermittently delivered a different product when a second
-// workgroup shared the CU (two waves of different workgroups per SIMD): identical operands, results differing
-// from run to run in the d/dx stream (tools/dbg notes in profiles/r02_packed_opsel.md).  The scalar forms cost
-// ~45 issue cycles per tile and wave (1.5 %) and are bitwise reproducible.
+// Broadcast scalars and packed fp32 arithmetic.  Written as f32x4 expressions, `vector * scalar` makes hipcc
+// broadcast a scalar that sits in the ODD register of a pair with v_pk_mul_f32 / v_pk_fma_f32 ... op_sel:[0,1]
+// (the LOW result lane reading the HIGH dword of the operand pair).  On MI355X those instructions intermittently
+// computed with 0 in place of that dword: frequently when the pair had just been returned by a ds_read_b128, rarely
+// with VALU-produced operands when a second workgroup shared the CU -- k_trunk2 gave run-to-run different d/dx-stream
+// values at full grids until this was found (profiles/r02_packed_opsel.md, tools/opselbench).  Two remedies here:
+// k_trunk2 loads its ring values so that each sits in the LOW half of a pair (ring_pairs: the safe op_sel_hi:[1,0]
+// broadcast, all arithmetic stays packed); k_trunkD (no registers to spare for that) and k_trunk16 (orbital values
+// are VALU results in arbitrary registers) do that arithmetic on unpacked instructions (lin2*, fmac_bcast*).
+// The eight stream values of one point record of the LDS ring (two orbitals x NST streams, consecutive floats at
+// LDS byte address `addr`), each as the LOW element of a register pair of its own: ds_read2_b32 with the wanted
+// dword first.  A scalar that sits in the low half of an aligned pair is broadcast by hipcc with op_sel_hi:[1,0];
+// one in the high half (every second value of a ds_read_b128) with the op_sel:[0,1] form described above.
+// tests/test_host_cpu.py checks the compiled kernels for that form.  (Waits for all of the wave's LDS operations.)
+__device__ __forceinline__ void ring_pairs(unsigned addr, float (&in)[2][NST])
+{
+    static_assert(NST == 4, "eight stream values per record");
+    typedef unsigned long long u64;
+    u64 p0, p1, p2, p3, p4, p5, p6, p7;
+    asm volatile("ds_read2_b32 %0, %8 offset0:0 offset1:1\n\tds_read2_b32 %1, %8 offset0:1 offset1:0\n\t"
+                 "ds_read2_b32 %2, %8 offset0:2 offset1:3\n\tds_read2_b32 %3, %8 offset0:3 offset1:2\n\t"
+                 "ds_read2_b32 %4, %8 offset0:4 offset1:5\n\tds_read2_b32 %5, %8 offset0:5 offset1:4\n\t"
+                 "ds_read2_b32 %6, %8 offset0:6 offset1:7\n\tds_read2_b32 %7, %8 offset0:7 offset1:6\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7)
+                 : "v"(addr) : "memory");
+    in[0][0] = __builtin_bit_cast(float, (unsigned)p0); in[0][1] = __builtin_bit_cast(float, (unsigned)p1);
+    in[0][2] = __builtin_bit_cast(float, (unsigned)p2); in[0][3] = __builtin_bit_cast(float, (unsigned)p3);
+    in[1][0] = __builtin_bit_cast(float, (unsigned)p4); in[1][1] = __builtin_bit_cast(float, (unsigned)p5);
+    in[1][2] = __builtin_bit_cast(float, (unsigned)p6); in[1][3] = __builtin_bit_cast(float, (unsigned)p7);
+}
+
 // hipcc's hazard recognizer does not look into inline assembly: the operands of these helpers must not be results
-// of MFMA instructions (the callers pass weights, point-record values and results of ordinary VALU arithmetic), and
-// only the _t variants (one asm block, opened by a wait state) may be given the result of a transcendental
-// instruction, which a VALU instruction may read one wait state later at the earliest on gfx940+ -- the orbital
-// values computed inline in k_trunk16 are such results; the ring-fed kernels read theirs from LDS.
+// of MFMA instructions (the callers pass weights, orbital values and results of ordinary VALU arithmetic); each is ONE
+// asm block opened by a wait state, because an operand may be the result of the transcendental instruction right
+// before it (the orbital values are), which a VALU instruction may read one wait state later at the earliest.
+// (lin2 / fmac_bcast: the same on separate, schedulable asm statements without the wait state -- only for operands
+// that are not transcendental results: k_trunkD's ring values, where ring_pairs' eight extra registers cost more
+// than these instructions do)
 __device__ __forceinline__ f32x4 lin2(f32x4 w0, float x0, f32x4 w1, float x1)   // w0 * x0 + w1 * x1
 {
     f32x4 r;
@@ -1309,10 +1336,8 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         unsigned mkpt;
         {
             const float* rp = ring + ((int)(itx % RB) * 16 + c) * RECF;
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4),
-                        r2 = *reinterpret_cast<const f32x4*>(rp + 8);
-#pragma unroll
-            for (int s = 0; s < NST; s++) { inA[0][s] = r0[s]; inA[1][s] = r1[s]; }
+            const f32x4 r2 = *reinterpret_cast<const f32x4*>(rp + 8);
+            ring_pairs((unsigned)(C::OFF_R + (size_t)(((int)(itx % RB) * 16 + c) * RECF) * 4), inA);
             Usum = r2[0]; Ept = r2[1]; gpt = r2[2]; mkpt = (unsigned)r2[3];
         }
         const float F = inA[0][0] + A.P * inA[1][0];
@@ -1323,9 +1348,9 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         for (int ps = 0; ps < 2; ps++) {
             f32x4 a[NST];
 #pragma unroll
-            for (int s = 1; s < NST; s++) a[s] = lin2(w0, inA[ps][s], w1, inA[1 - ps][s]);
+            for (int s = 1; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
             f32x4 s0, s1, s2;
-            act012v_scaled<ACT>(lin2(w0e, inA[ps][0], w1e, inA[1 - ps][0]) + b0e, s0, s1, s2);
+            act012v_scaled<ACT>(w0e * inA[ps][0] + w1e * inA[1 - ps][0] + b0e, s0, s1, s2);
             const f32x4 q = a[1] * a[1] + a[2] * a[2];
             h0[ps] = s0;
             put(XB + ps * EB, 0, s0);
@@ -1435,7 +1460,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             for (int ps = 0; ps < 2; ps++) {
                 f32x4 a[NST];
 #pragma unroll
-                for (int s = 1; s < NST; s++) a[s] = lin2(w0, inA[ps][s], w1, inA[1 - ps][s]);
+                for (int s = 1; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
                 f32x4 s1, s2, s3;
                 act123v<ACT>(h0[ps], s1, s2, s3);
                 const f32x4 q = a[1] * a[1] + a[2] * a[2];
@@ -1447,7 +1472,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 ab[0] = s1 * ob[ps][0] + s2 * (a[1] * ob[ps][1] + a[2] * ob[ps][2]) + (s2 * a[SLP] + s3 * q) * ob[ps][SLP];
                 bacc0 += ab[0];
 #pragma unroll
-                for (int s = 0; s < NST; s++) { fmac_bcast(w0acc0, ab[s], inA[ps][s]); fmac_bcast(w0acc1, ab[s], inA[1 - ps][s]); }
+                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * inA[ps][s]; w0acc1 += ab[s] * inA[1 - ps][s]; }
             }
         }
         if (C::XSETS == 1) __syncthreads();   // one set of layer-output buffers: P1 of the next tile overwrites it

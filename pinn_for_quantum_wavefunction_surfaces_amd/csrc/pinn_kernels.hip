@@ -863,7 +863,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
-constexpr int kSampleBlock = 1024;   // few, large blocks: the two count atomics per block hit one address
+constexpr int kSampleBlock = 1024;   // few, large blocks
+constexpr int kSampleMaxBlocks = 256;
 __global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t step0,
                                                    const int32_t* __restrict__ step_dev, int64_t first,
                                                    int64_t n, float box, float Rlo, float Rhi,
@@ -871,7 +872,8 @@ __global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t
                                                    float* __restrict__ x, float* __restrict__ y,
                                                    float* __restrict__ z, float* __restrict__ R,
                                                    uint8_t* __restrict__ mask,
-                                                   unsigned long long* __restrict__ counts)
+                                                   unsigned long long* __restrict__ counts,
+                                                   unsigned long long* __restrict__ part)
 {
     const uint64_t step = step0 + (step_dev ? (uint64_t)(int64_t)*step_dev : 0);
     const float two_box = box + box, dR = Rhi - Rlo;
@@ -902,8 +904,11 @@ __global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t
         c2 += (mk >> 1) & 1;
     }
     if (counts) {
-        // integer sums: order-independent, so atomics stay deterministic
+        // per-block partial counts, summed by whichever block finishes last (ticket): no memset of the counts
+        // before the kernel (a 5 us node of its own in every step), no atomics on them; integer sums, so the
+        // result does not depend on the order
         __shared__ unsigned sh[2];
+        __shared__ unsigned last;
         if (threadIdx.x < 2) sh[threadIdx.x] = 0;
         __syncthreads();
         unsigned w1 = c1, w2 = c2;
@@ -915,8 +920,29 @@ __global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t
         if ((threadIdx.x & 63) == 0) { atomicAdd(&sh[0], w1); atomicAdd(&sh[1], w2); }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(&counts[0], (unsigned long long)sh[0]);
-            atomicAdd(&counts[1], (unsigned long long)sh[1]);
+            __hip_atomic_store(&part[2 * blockIdx.x], (unsigned long long)sh[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&part[2 * blockIdx.x + 1], (unsigned long long)sh[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            last = atomicAdd(reinterpret_cast<unsigned*>(part + 2 * kSampleMaxBlocks), 1u) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (last && threadIdx.x < 64) {
+            __threadfence();
+            unsigned long long s1 = 0, s2 = 0;
+            for (unsigned b = threadIdx.x; b < gridDim.x; b += 64) {
+                s1 += __hip_atomic_load(&part[2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s2 += __hip_atomic_load(&part[2 * b + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                s1 += (unsigned long long)__shfl_xor((long long)s1, off, kWave);
+                s2 += (unsigned long long)__shfl_xor((long long)s2, off, kWave);
+            }
+            if (threadIdx.x == 0) {
+                counts[0] = s1;
+                counts[1] = s2;
+                *reinterpret_cast<unsigned*>(part + 2 * kSampleMaxBlocks) = 0;   // ticket for the next call
+            }
         }
     }
 }
@@ -983,6 +1009,7 @@ struct pinn_handle {
     float *partT, *partR;   // per-block partials
     void* wpk;              // packed bf16 weights (MFMA path)
     float* thT;             // theta with forward matrices input-major (k_prep_theta)
+    unsigned long long* samp; // k_sample: per-block partial counts [2 * 256] + ticket
     uint8_t* tensor_of;     // [P] tensor index of each parameter
     uint64_t trunk_tensors; // bits of the trunk tensors
     int prof_slots;          // 0 = off
@@ -1265,6 +1292,8 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     HIPCHK(h, hipMalloc(&h->partR, sizeof(float) * (size_t)h->nbR * h->strideR));
     HIPCHK(h, hipMalloc(&h->tensor_of, h->P));
     HIPCHK(h, hipMalloc(&h->thT, sizeof(float) * h->P));
+    HIPCHK(h, hipMalloc(&h->samp, sizeof(unsigned long long) * (2 * kSampleMaxBlocks + 1)));
+    HIPCHK(h, hipMemset(h->samp, 0, sizeof(unsigned long long) * (2 * kSampleMaxBlocks + 1)));
     if (arch->precision != PINN_PREC_F32)
         HIPCHK(h, hipMalloc(&h->wpk, mfma_packed_weight_bytes(arch->H, arch->L) +
                                          mfma_stash_bytes(arch->H, arch->L, arch->precision == PINN_PREC_BF16X3, h->nbT)));
@@ -1342,6 +1371,7 @@ extern "C" int pinn_destroy(pinn_handle* h)
     (void)hipFree(h->partT); (void)hipFree(h->partR); (void)hipFree(h->tensor_of);
     if (h->wpk) (void)hipFree(h->wpk);
     (void)hipFree(h->thT);
+    if (h->samp) (void)hipFree(h->samp);
     delete h;
     return PINN_OK;
 }
@@ -1476,11 +1506,10 @@ extern "C" int pinn_sample(pinn_handle* h, uint64_t seed, uint64_t step, const i
     if (!h) return PINN_ERR_ARG;
     if (!x || !y || !z || !R || n < 1 || first < 0) return fail(h, PINN_ERR_ARG, "null pointer or bad range");
     hipStream_t st = (hipStream_t)stream;
-    if (counts) HIPCHK(h, hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), st));
     const int64_t sblocks = (n + kSampleBlock - 1) / kSampleBlock;
-    hipLaunchKernelGGL(k_sample, dim3((unsigned)(sblocks < 256 ? sblocks : 256)), dim3(kSampleBlock), 0, st, seed, step, step_dev, first, n,
-                       box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
-                       (unsigned long long*)counts);
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)(sblocks < kSampleMaxBlocks ? sblocks : kSampleMaxBlocks)), dim3(kSampleBlock), 0, st,
+                       seed, step, step_dev, first, n, box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
+                       (unsigned long long*)counts, h->samp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_sample", e);
     return PINN_OK;

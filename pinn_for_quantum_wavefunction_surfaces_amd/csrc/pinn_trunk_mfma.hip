@@ -1337,7 +1337,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         {
             const float* rp = ring + ((int)(itx % RB) * 16 + c) * RECF;
             const f32x4 r2 = *reinterpret_cast<const f32x4*>(rp + 8);
-            ring_pairs((unsigned)(C::OFF_R + (size_t)(((int)(itx % RB) * 16 + c) * RECF) * 4), inA);
+            ring_pairs((unsigned)(uintptr_t)(lds0 + C::OFF_R) + (unsigned)((((int)(itx % RB) * 16 + c) * RECF) * 4), inA);
             Usum = r2[0]; Ept = r2[1]; gpt = r2[2]; mkpt = (unsigned)r2[3];
         }
         const float F = inA[0][0] + A.P * inA[1][0];

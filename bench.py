@@ -87,6 +87,10 @@ ARCHS = {
 ARCHS["ref16ft"] = dict(ARCHS["ref16"], fine_tune=True,
                         label="reference arch, fine-tune mode: trunk + gate frozen, only the E-net trains "
                               "(forward-only trunk sweep), R in [0.5, 4], ionHsym weights, fp32")
+# train.py's own formulation (single pass over (f1, f2), output 2h, coefficients (1, 1, 1)) at 2x64 tanh
+ARCHS["wide64B"] = dict(ARCHS["wide64"], n_pass=1, out_scale=2.0, formulation="B",
+                        label="train.py's formulation (single pass, 2h): 2x64 tanh trunk + 2x32 E-net + 1x10 gate, "
+                              "bf16 MFMA trunk with fp32 accumulate, seeded random init")
 ARCHS["wide128"] = dict(H=128, L=2, HE=32, HG=10, act=1, n_pass=2, out_scale=1.0, precision="bf16",
                         act_name="tanh", peak=2500.0, dtype="bf16",
                         label="2x128 tanh trunk + 2x32 E-net + 1x10 gate, bf16 MFMA trunk with fp32 "
@@ -130,6 +134,8 @@ DEFAULT_ARCH = "wide64"
 
 def _mfma_kernel_name(arch):
     """the trunk kernel launch_trunk_mfma dispatches this workload to (csrc/pinn_trunk_mfma.hip)"""
+    if arch.get("n_pass", 2) == 1 and arch["L"] == 2 and arch.get("precision") == "bf16" and not arch.get("fine_tune", False):
+        return "k_trunk2 (single pass: two tiles per trip)"
     if arch.get("n_pass", 2) == 2 and not arch.get("fine_tune", False):
         if arch["L"] == 2:
             if arch.get("precision") == "bf16x3":
@@ -138,7 +144,7 @@ def _mfma_kernel_name(arch):
         if arch["L"] == 4 and arch.get("precision") != "bf16x3":
             return "k_trunkD"
     return "k_trunk_mfma2"
-SECONDARY = {"wide64": ["wide64x3", "wide4x128x3", "ref16", "ref16ft", "wide128", "wide4x64", "wide4x128"], "ref16": ["wide64"], "wide64x3": ["wide64"],
+SECONDARY = {"wide64": ["wide64x3", "wide4x128x3", "ref16", "ref16ft", "wide128", "wide4x64", "wide4x128", "wide64B"], "ref16": ["wide64"], "wide64x3": ["wide64"],
              "wide128": ["wide128x3"], "wide128x3": ["wide128"]}
 # tolerances the GPU parity tests hold each path to, against the fp64 oracle / reference vectors
 # (tests/test_gpu_parity.py).  What THIS run observed is measured in the cpu_baseline leg ("parity_observed").
@@ -279,7 +285,7 @@ def main():
         a = ARCHS[name]
         torch.manual_seed(12345)
         m = pkg.NN_ion(params, a["H"], a["HE"], a["HG"], n_hidden=a["L"], act=a["act_name"],
-                       precision=a["precision"]).to(dev)
+                       formulation=a.get("formulation", "A"), precision=a["precision"]).to(dev)
         if name.startswith("ref16"):
             m.load_flat_params(torch.tensor(np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))["ionHsym"]))
         return m

@@ -252,6 +252,14 @@ __device__ __forceinline__ void fmac_bcast(f32x4& acc, f32x4 v, float x)        
     for (int k = 0; k < 4; k++) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[k]) : "v"(v[k]), "v"(x));
 }
 
+__device__ __forceinline__ f32x4 mul_bcast(f32x4 v, float x)                     // v * x
+{
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) asm("v_mul_f32 %0, %1, %2" : "=v"(r[k]) : "v"(v[k]), "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ f32x4 lin2_t(f32x4 w0, float x0, f32x4 w1, float x1)
 {
     float r0, r1, r2, r3;
@@ -1170,20 +1178,24 @@ struct T2Cfg {
     // its 4 lane groups) computes the same 16 points' orbitals in every trip
     static constexpr int RB = 4 * WAVES, RECF = 12;
     static constexpr int RBYTES = RB * 16 * RECF * 4;
-    static constexpr int XSETS = (OCC * (WBYTES + NSMALL * 4 + 6 * EB + RBYTES + 1024) <= 160 * 1024) ? 2 : 1;
+    static constexpr int XSETS = (OCC * (WBYTES + NSMALL * 4 + 6 * EB + RBYTES + 2048) <= 160 * 1024) ? 2 : 1;
     static constexpr size_t OFF_SMALL = WBYTES;
     static constexpr size_t OFF_X = OFF_SMALL + NSMALL * 4;
     static constexpr size_t OFF_Y = OFF_X + (size_t)XSETS * 2 * EB;
     static constexpr size_t OFF_S = OFF_Y + 2 * EB;
-    static constexpr size_t OFF_R = OFF_S + WAVES * 16 * 2 * 4;
+    static constexpr size_t OFF_R = OFF_S + WAVES * 16 * 2 * 2 * 4;       // S: [wave][16 points][2 tiles][Sv, Sl]
     static constexpr size_t LDS_BYTES = OFF_R + RBYTES;
     static_assert(OCC * LDS_BYTES <= 160 * 1024, "k_trunk2 does not fit the CU's LDS");
 };
 
-template <int H, int ACT>
+// TT (train.py's formulation: ONE pass per point over (f1, f2), output 2h): the two 64-column halves of every
+// phase are two TILES instead of the two passes of one tile -- same GEMMs, barriers and buffers; each tile has its
+// own record, output sums and tail, and the layer-0 inputs are not swapped.
+template <int H, int ACT, bool TT = false>
 __global__ __launch_bounds__(T2Cfg<H>::WAVES * 64, T2Cfg<H>::OCC * T2Cfg<H>::WAVES / 4)
 void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, TrunkArgs A)
 {
+    constexpr int NTL = TT ? 2 : 1;             // tiles per trip
     using C = T2Cfg<H>;
     using Lay = TrunkLayout<H, 2>;
     constexpr int HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB;
@@ -1197,7 +1209,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     float* sb1 = small + 3 * H;
     float* swo = small + 4 * H;
     float* sbo = small + 5 * H;
-    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_S);   // [wave][16 points][2]
+    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_S);   // [wave][16 points][tile][2]
 
     const int lane = threadIdx.x & 63;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row tile owned by this wave
@@ -1246,9 +1258,10 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     }
     const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
-    const int64_t iters = (ntile + gridDim.x - 1) / gridDim.x;   // same for every block: barriers match
+    const int64_t iters = (ntile + NTL * gridDim.x - 1) / (NTL * gridDim.x);   // same for every block: barriers match
 
-    // ring batch b covers trips b*RB .. b*RB + RB-1; this lane's point of it: trip b*RB + 4*part + g, column c
+    // ring batch b covers the block's tiles b*RB .. b*RB + RB-1 (NTL per trip); this lane's point of it: tile
+    // b*RB + 4*part + g, column c
     constexpr int RB = C::RB, RECF = C::RECF;
     float* ring = reinterpret_cast<float*>(lds_raw + C::OFF_R);
     struct PointRec { float x, y, z, R, E, g; unsigned mk; };
@@ -1318,39 +1331,54 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     int xset = 0;
     for (int64_t itx = 0; itx < iters; itx++) {
         T2_STAMP(7);
-        const int64_t tile = itx * gridDim.x + blockIdx.x;
+        const int64_t tile = (NTL * itx) * gridDim.x + blockIdx.x;      // (TT: the first of the trip's two tiles)
         const int64_t idx = tile * 16 + c;
         const bool valid = tile < ntile && idx < A.n;
-        if (itx % RB == 0) {
+        const int slot0 = (int)((NTL * itx) % RB);                       // ring slot of that tile
+        if (slot0 == 0) {
             // refill: the last reads of the previous batch (P1, P3 of the previous trip) lie before that
-            // trip's third barrier, which every wave has passed
+            // trip's third barrier, which every wave has passed -- except in TT mode, whose P4 reads the records again
+            // (keeping both tiles' records in registers instead was measured: spills, no faster)
+            if (TT && itx) __syncthreads();
             fill_ring(nxt);
-            nxt = load_rec(itx / RB + 1);       // raw points of the next batch: nothing waits for them for RB trips
+            nxt = load_rec(NTL * itx / RB + 1); // raw points of the next batch: nothing waits for them for RB trips
             __syncthreads();
         }
         const lds_p XB = lds0 + C::OFF_X + (size_t)(C::XSETS == 2 ? xset : 0) * 2 * EB;   // [pass] at + ps * EB
         const lds_p YB = lds0 + C::OFF_Y;
         // ================= P1: inputs and layer 0 of both passes =================
+        const unsigned ring_a0 = (unsigned)(uintptr_t)(lds0 + C::OFF_R) + (unsigned)(((slot0 * 16 + c) * RECF) * 4);
         float inA[2][NST];
-        float Usum, Ept, gpt;
-        unsigned mkpt;
-        {
-            const float* rp = ring + ((int)(itx % RB) * 16 + c) * RECF;
+        float Usum = 0.f, Ept = 0.f, gpt = 0.f, F = 0.f, lapF = 0.f;
+        unsigned mkpt = 0;
+        if constexpr (!TT) {
+            const float* rp = ring + (slot0 * 16 + c) * RECF;
             const f32x4 r2 = *reinterpret_cast<const f32x4*>(rp + 8);
-            ring_pairs((unsigned)(uintptr_t)(lds0 + C::OFF_R) + (unsigned)((((int)(itx % RB) * 16 + c) * RECF) * 4), inA);
+            ring_pairs(ring_a0, inA);
             Usum = r2[0]; Ept = r2[1]; gpt = r2[2]; mkpt = (unsigned)r2[3];
+            F = inA[0][0] + A.P * inA[1][0];
+            lapF = inA[0][SLP] + A.P * inA[1][SLP];
         }
-        const float F = inA[0][0] + A.P * inA[1][0];
-        const float lapF = inA[0][SLP] + A.P * inA[1][SLP];
+        // the two inputs of half `ps` of the tile columns: (f1, f2) streams in the order the half's layer 0 takes them
+        auto inputs = [&](int ps, float (&f)[2][NST]) {
+            if constexpr (TT) {
+                ring_pairs(ring_a0 + ps * 16 * RECF * 4, f);              // the record of tile ps of this trip
+            } else {
+#pragma unroll
+                for (int s = 0; s < NST; s++) { f[0][s] = inA[ps][s]; f[1][s] = inA[1 - ps][s]; }
+            }
+        };
         f32x4 h0[2];            // layer-0 activations of the own neurons, pass A / pass B
         f32x4 sv[2][NST];       // (h, a_x, a_rho, a_lap) of layer 1
 #pragma unroll
         for (int ps = 0; ps < 2; ps++) {
+            float f[2][NST];
+            inputs(ps, f);
             f32x4 a[NST];
 #pragma unroll
-            for (int s = 1; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
+            for (int s = 1; s < NST; s++) a[s] = w0 * f[0][s] + w1 * f[1][s];
             f32x4 s0, s1, s2;
-            act012v_scaled<ACT>(w0e * inA[ps][0] + w1e * inA[1 - ps][0] + b0e, s0, s1, s2);
+            act012v_scaled<ACT>(w0e * f[0][0] + w1e * f[1][0] + b0e, s0, s1, s2);
             const f32x4 q = a[1] * a[1] + a[2] * a[2];
             h0[ps] = s0;
             put(XB + ps * EB, 0, s0);
@@ -1381,40 +1409,65 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 sv[ps][0] = s0;
 #pragma unroll
                 for (int s = 1; s < NST; s++) sv[ps][s] = acc[ps][s];
-                const float pw = ps ? A.P : 1.0f;
-                Sv += pw * dot4(wo, s0);
-                Sl += pw * dot4(wo, ol);
+                if constexpr (TT) {                          // every tile has its own output
+                    const float tot = xg_sum_pair(dot4(wo, s0), dot4(wo, ol));
+                    if ((g & 1) == 0) SB[((part * 16 + c) * 2 + ps) * 2 + (g >> 1)] = tot;
+                } else {
+                    const float pw = ps ? A.P : 1.0f;
+                    Sv += pw * dot4(wo, s0);
+                    Sl += pw * dot4(wo, ol);
+                }
             }
-            const float tot = xg_sum_pair(Sv, Sl);          // Sv in lane groups 0,1; Sl in groups 2,3
-            if ((g & 1) == 0) SB[(part * 16 + c) * 2 + (g >> 1)] = tot;
+            if constexpr (!TT) {
+                const float tot = xg_sum_pair(Sv, Sl);      // Sv in lane groups 0,1; Sl in groups 2,3
+                if ((g & 1) == 0) SB[((part * 16 + c) * 2) * 2 + (g >> 1)] = tot;
+            }
         }
         T2_STAMP(2);
         __syncthreads();
         T2_STAMP(3);
         // ================= P3: tail, last hidden layer's adjoints of both passes =================
         Tail<float> t;
-        {
+        auto do_tail = [&](int tl) {                 // tail of tile `tl` of the trip (0 unless TT)
             float Sv = 0.f, Sl = 0.f;
 #pragma unroll
-            for (int pp = 0; pp < C::WAVES; pp++) { Sv += SB[(pp * 16 + c) * 2]; Sl += SB[(pp * 16 + c) * 2 + 1]; }
-            tail<float>(A.out_scale * Sv + bout, A.out_scale * Sl, gpt, Ept, F, lapF, Usum, A.a, A.b, A.c,
-                        float(mkpt & 1), float((mkpt >> 1) & 1), A.invN, invN1, invN2, valid ? 1.0f : 0.0f, t);
-            if (valid && g == 0 && part == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+            for (int pp = 0; pp < C::WAVES; pp++) { Sv += SB[((pp * 16 + c) * 2 + tl) * 2]; Sl += SB[((pp * 16 + c) * 2 + tl) * 2 + 1]; }
+            if constexpr (TT) {
+                const float* rp = ring + ((slot0 + tl) * 16 + c) * RECF;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4),
+                            r2 = *reinterpret_cast<const f32x4*>(rp + 8);
+                const int64_t tile_t = tile + (int64_t)tl * gridDim.x, idx_t = tile_t * 16 + c;
+                const bool valid_t = tile_t < ntile && idx_t < A.n;
+                const unsigned mk = (unsigned)r2[3];
+                tail<float>(A.out_scale * Sv + bout, A.out_scale * Sl, r2[2], r2[1], r0[0] + A.P * r1[0], r0[SLP] + A.P * r1[SLP],
+                            r2[0], A.a, A.b, A.c, float(mk & 1), float((mk >> 1) & 1), A.invN, invN1, invN2,
+                            valid_t ? 1.0f : 0.0f, t);
+                if (valid_t && g == 0 && part == 0) { A.Eb[idx_t] = t.Eb; A.gb[idx_t] = t.gb; }
+            } else {
+                tail<float>(A.out_scale * Sv + bout, A.out_scale * Sl, gpt, Ept, F, lapF, Usum, A.a, A.b, A.c,
+                            float(mkpt & 1), float((mkpt >> 1) & 1), A.invN, invN1, invN2, valid ? 1.0f : 0.0f, t);
+                if (valid && g == 0 && part == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+            }
             acc_pde += lead * t.l_pde;
             acc_bc1 += lead * t.l_bc1;
             acc_bc2 += lead * t.l_bc2;
             acc_bout += lead * t.Nb;
-        }
+        };
+        if constexpr (!TT) do_tail(0);
 #pragma unroll
         for (int ps = 0; ps < 2; ps++) {
-            const float pw = ps ? A.P : 1.0f;
+            if constexpr (TT) do_tail(ps);
+            const float pw = (!TT && ps) ? A.P : 1.0f;
             const float cv = A.out_scale * pw * t.Nb, cl = A.out_scale * pw * t.lapNb;
             const f32x4 h = sv[ps][0];
             f32x4 s1, s2, s3;
             act123v<ACT>(h, s1, s2, s3);
             const f32x4 q = sv[ps][1] * sv[ps][1] + sv[ps][2] * sv[ps][2];
-            woacc += cv * h + cl * (s1 * sv[ps][SLP] + s2 * q);
-            const f32x4 o0 = cv * wo, ol = cl * wo;
+            // (TT: the per-tile scalars cv, cl ended up in odd registers and hipcc broadcast them with the unsafe
+            // op_sel:[0,1] form -- the CPU test of the assembly caught it; unpacked multiplies there)
+            auto smul = [&](f32x4 v, float x) { if constexpr (TT) return mul_bcast(v, x); else return x * v; };
+            woacc += smul(h, cv) + smul(s1 * sv[ps][SLP] + s2 * q, cl);
+            const f32x4 o0 = smul(wo, cv), ol = smul(wo, cl);
             const f32x4 u = 2.0f * s2 * ol;
             const f32x4 y0 = s1 * o0 + (s2 * sv[ps][SLP] + s3 * q) * ol;
             bacc1 += y0;
@@ -1458,9 +1511,11 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             gemm8(wbwd, YB, ob);
 #pragma unroll
             for (int ps = 0; ps < 2; ps++) {
+                float f[2][NST];
+                inputs(ps, f);
                 f32x4 a[NST];
 #pragma unroll
-                for (int s = 1; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
+                for (int s = 1; s < NST; s++) a[s] = w0 * f[0][s] + w1 * f[1][s];
                 f32x4 s1, s2, s3;
                 act123v<ACT>(h0[ps], s1, s2, s3);
                 const f32x4 q = a[1] * a[1] + a[2] * a[2];
@@ -1472,7 +1527,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 ab[0] = s1 * ob[ps][0] + s2 * (a[1] * ob[ps][1] + a[2] * ob[ps][2]) + (s2 * a[SLP] + s3 * q) * ob[ps][SLP];
                 bacc0 += ab[0];
 #pragma unroll
-                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * inA[ps][s]; w0acc1 += ab[s] * inA[1 - ps][s]; }
+                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * f[0][s]; w0acc1 += ab[s] * f[1][s]; }
             }
         }
         if (C::XSETS == 1) __syncthreads();   // one set of layer-output buffers: P1 of the next tile overwrites it
@@ -1528,7 +1583,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     if (threadIdx.x == 3) out[Lay::bout] = sc[3];
 }
 
-template <int H, int ACT>
+template <int H, int ACT, bool TT = false>
 hipError_t launch_trunk2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
 {
     using C1 = MCfg<H, 2>;
@@ -1537,7 +1592,7 @@ hipError_t launch_trunk2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, 
     hipLaunchKernelGGL((k_pack_weights<H, 2, false>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    auto kern = k_trunk2<H, ACT>;
+    auto kern = k_trunk2<H, ACT, TT>;
     static bool attr_set[64] = {};   // per device (not a stream operation: done outside graph capture)
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -3213,6 +3268,14 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
             return launch2_HL<128, 2, 8, 8, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
         }
         return false;
+    }
+    if (L == 2 && npass == 1 && mode == MODE_BWD && mfma_variant() != 3 && (H == 64 || H == 128)) {
+        // train.py's formulation (one pass per point): the same kernel with two tiles per trip
+        if (H == 64) *err = act == ACT_TANH ? launch_trunk2_t<64, ACT_TANH, true>(theta, wpk, A, grid, st)
+                                            : launch_trunk2_t<64, ACT_SIGMOID, true>(theta, wpk, A, grid, st);
+        else *err = act == ACT_TANH ? launch_trunk2_t<128, ACT_TANH, true>(theta, wpk, A, grid, st)
+                                    : launch_trunk2_t<128, ACT_SIGMOID, true>(theta, wpk, A, grid, st);
+        return true;
     }
     if (L == 2 && npass == 2 && mode == MODE_BWD && mfma_variant() != 3 && (H == 64 || H == 128)) {
         // the benchmark's shape: both passes swept together (k_trunk2)

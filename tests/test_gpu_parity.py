@@ -599,6 +599,41 @@ def test_merged_pass_kernels_ragged_sizes(n, prec):
 
 
 @pytest.mark.parametrize("H", [64, 128])
+@pytest.mark.parametrize("n", [1, 17, 33, 4113, 300000])
+def test_single_pass_two_tile_mode_ragged_sizes_and_ring_refill(H, n):
+    """train.py's formulation (one pass per point) on k_trunk2's two-tiles-per-trip mode: sizes that leave the second
+    tile of a trip, tiles and ring batches partly empty, and 300 000 points (ring refills; the extra barrier before
+    them): loss and gradient against the oracle at the bf16 tolerance (small sizes) and against the pass-by-pass
+    kernel (PINN_MFMA_VARIANT=3) to well inside that tolerance."""
+    A = O.arch(H=H, L=2, act=1, n_pass=1, out_scale=2.0)
+    rng = np.random.default_rng(277 + n + H)
+    off, sz = O.tensor_layout(A)
+    theta = np.zeros(O.param_count(A))
+    fan = [2, 2, H, H, H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    for o, s_, fi in zip(off, sz, fan):
+        theta[o:o + s_] = rng.uniform(-1, 1, s_) / np.sqrt(fi)
+    x, y, z = rng.uniform(-18, 18, (3, n))
+    R = rng.uniform(0.2, 4, n)
+    mask = rng.integers(0, 4, n).astype(np.uint8)
+    f = pkg.model.FORMULATION_B
+    h = capi.Handle(capi.Arch(H, 2, 32, 10, 1, 1, 2.0, capi.PINN_PREC_BF16), 0, max(n, 8192))
+    try:
+        os.environ["PINN_MFMA_VARIANT"] = "0"
+        out = run_loss_grad(h, f, theta, x, y, z, R, mask)
+        os.environ["PINN_MFMA_VARIANT"] = "3"
+        old = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    finally:
+        os.environ.pop("PINN_MFMA_VARIANT", None)
+    P = h.P
+    assert np.isfinite(out).all()
+    # (the pass-by-pass kernel saves its forward state as bf16 pairs at H = 128, as fp32 at H = 64)
+    assert abs(out[P:].sum() / old[P:].sum() - 1) < 2e-5 and rel(out[:P], old[:P]) < (1e-3 if H == 64 else 8e-3)
+    if n < 10000:
+        ref = O.loss_grad(A, O.ham_B(), theta, x, y, z, R, mask)
+        assert abs(out[P:].sum() / ref["Ltot"] - 1) < 5e-2 and rel(out[:P], ref["grad"]) < 5e-2
+
+
+@pytest.mark.parametrize("H", [64, 128])
 @pytest.mark.parametrize("n", [1, 17, 4113, 300000])
 def test_deep_trunk_kernel_ragged_sizes_and_ring_refill(H, n):
     """k_trunkD (4x64, 4x128 bf16) at sizes that leave tiles and ring batches partly empty, and at 300 000 points,
@@ -634,14 +669,16 @@ def test_deep_trunk_kernel_ragged_sizes_and_ring_refill(H, n):
 
 
 @pytest.mark.parametrize("H,L,prec", [(16, 2, "f32"), (64, 2, "bf16"), (64, 2, "bf16x3"), (128, 2, "bf16"),
-                                      (64, 4, "bf16"), (128, 4, "bf16")])
+                                      (64, 4, "bf16"), (128, 4, "bf16"), (64, 2, "bf16-B"), (128, 2, "bf16-B")])
 def test_bitwise_reproducible_with_co_resident_blocks(H, L, prec):
     """131 072 points = a full persistent grid (two workgroups per CU where the kernel is built for that): four
     calls with the same inputs return the same bits.  Round 2 found k_trunk2<64> differing from run to run in
     exactly this regime (packed fp32 op_sel forms on the point-record ring, see lin2 in csrc/pinn_trunk_mfma.hip);
     small batches, which place one workgroup per CU, never showed it."""
     n = 131072
-    A = O.arch(H=H, L=L, act=1)
+    form_b = prec.endswith("-B")            # train.py's formulation: one pass, two tiles per trip in k_trunk2
+    prec = prec.split("-")[0]
+    A = O.arch(H=H, L=L, act=1, n_pass=1, out_scale=2.0) if form_b else O.arch(H=H, L=L, act=1)
     rng = np.random.default_rng(5 + H + L)
     off, sz = O.tensor_layout(A)
     theta = np.zeros(O.param_count(A))
@@ -652,8 +689,8 @@ def test_bitwise_reproducible_with_co_resident_blocks(H, L, prec):
     R = rng.uniform(0.2, 3, n)
     mask = rng.integers(0, 4, n).astype(np.uint8)
     pr = {"f32": capi.PINN_PREC_F32, "bf16": capi.PINN_PREC_BF16, "bf16x3": capi.PINN_PREC_BF16X3}[prec]
-    h = capi.Handle(capi.Arch(H, L, 32, 10, 1, 2, 1.0, pr), 0, n)
-    f = pkg.model.FORMULATION_A
+    h = capi.Handle(capi.Arch(H, L, 32, 10, 1, 1, 2.0, pr) if form_b else capi.Arch(H, L, 32, 10, 1, 2, 1.0, pr), 0, n)
+    f = pkg.model.FORMULATION_B if form_b else pkg.model.FORMULATION_A
     runs = [run_loss_grad(h, f, theta, x, y, z, R, mask) for _ in range(4)]
     assert np.isfinite(runs[0]).all()
     for k in range(1, 4):

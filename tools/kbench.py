@@ -35,7 +35,7 @@ def main():
         os.environ["PINN_MFMA_VARIANT"] = str(v)
         torch.manual_seed(12345)
         m = pkg.NN_ion(params, a["H"], a["HE"], a["HG"], n_hidden=a["L"], act=a["act_name"],
-                       precision=a["precision"]).to(dev)
+                       formulation=a.get("formulation", "A"), precision=a["precision"]).to(dev)
         tr = pkg.Trainer(m, params, n_points=args.points, lr=8e-3, seed=12345, device=dev)
         tr.h.profile_enable(args.steps)
         for _ in range(30):

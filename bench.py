@@ -135,7 +135,7 @@ DEFAULT_ARCH = "wide64"
 def _mfma_kernel_name(arch):
     """the trunk kernel launch_trunk_mfma dispatches this workload to (csrc/pinn_trunk_mfma.hip)"""
     if arch.get("n_pass", 2) == 1 and arch["L"] == 2 and arch.get("precision") == "bf16" and not arch.get("fine_tune", False):
-        return "k_trunk2 (single pass: two tiles per trip)"
+        return "k_trunk2s"
     if arch.get("n_pass", 2) == 2 and not arch.get("fine_tune", False):
         if arch["L"] == 2:
             if arch.get("precision") == "bf16x3":

@@ -1765,6 +1765,7 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
             }
         };
         f32x4 h0[2];            // layer-0 activations of the own neurons, pass A / pass B
+        f32x4 a0k[2][NST];      // TT: layer-0 pre-activation streams 1..3 of both tiles, kept for P4
         f32x4 sv[2][NST];       // (h, a_x, a_rho, a_lap) of layer 1
 #pragma unroll
         for (int ps = 0; ps < 2; ps++) {
@@ -1777,6 +1778,10 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
             act012v_scaled<ACT>(w0e * f[0][0] + w1e * f[1][0] + b0e, s0, s1, s2);
             const f32x4 q = a[1] * a[1] + a[2] * a[2];
             h0[ps] = s0;
+            if constexpr (TT) {
+#pragma unroll
+                for (int s = 1; s < NST; s++) a0k[ps][s] = a[s];
+            }
             put(XB + ps * EB, 0, s0);
             put(XB + ps * EB, 1, s1 * a[1]);
             put(XB + ps * EB, 2, s1 * a[2]);
@@ -1908,10 +1913,21 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
 #pragma unroll
             for (int ps = 0; ps < 2; ps++) {
                 float f[2][NST];
-                inputs(ps, f);
                 f32x4 a[NST];
+                if constexpr (TT) {
+                    // the tile's record again as plain 16-byte reads (its values are only multiplied by unpacked
+                    // instructions below); the pre-activation streams were kept from P1
+                    const float* rp = ring + ((slot0 + ps) * 16 + c) * RECF;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
-                for (int s = 1; s < NST; s++) a[s] = w0 * f[0][s] + w1 * f[1][s];
+                    for (int s = 0; s < NST; s++) { f[0][s] = r0[s]; f[1][s] = r1[s]; }
+#pragma unroll
+                    for (int s = 1; s < NST; s++) a[s] = a0k[ps][s];
+                } else {
+                    inputs(ps, f);
+#pragma unroll
+                    for (int s = 1; s < NST; s++) a[s] = w0 * f[0][s] + w1 * f[1][s];
+                }
                 f32x4 s1, s2, s3;
                 act123v<ACT>(h0[ps], s1, s2, s3);
                 const f32x4 q = a[1] * a[1] + a[2] * a[2];
@@ -1923,7 +1939,10 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 ab[0] = s1 * ob[ps][0] + s2 * (a[1] * ob[ps][1] + a[2] * ob[ps][2]) + (s2 * a[SLP] + s3 * q) * ob[ps][SLP];
                 bacc0 += ab[0];
 #pragma unroll
-                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * f[0][s]; w0acc1 += ab[s] * f[1][s]; }
+                for (int s = 0; s < NST; s++) {
+                    if constexpr (TT) { fmac_bcast(w0acc0, ab[s], f[0][s]); fmac_bcast(w0acc1, ab[s], f[1][s]); }
+                    else { w0acc0 += ab[s] * f[0][s]; w0acc1 += ab[s] * f[1][s]; }
+                }
             }
         }
         if (C::XSETS == 1) __syncthreads();   // one set of layer-output buffers: P1 of the next tile overwrites it

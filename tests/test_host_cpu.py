@@ -193,3 +193,8 @@ def test_no_packed_opsel_forms_in_the_matrix_pipe_kernels():
     assert sum(tot.values()) > 10000          # the scan saw the kernels
     bad = {k: v for k, v in hits.items() if v}
     assert not bad, "packed op_sel forms in: %s" % sorted(bad)[:5]
+    # and, while the assembly is at hand: the kernels of the benchmark's primary workload, of train.py's formulation
+    # and of the reference architecture do not spill (a silent performance regression otherwise)
+    for sym in ("8k_trunk2ILi64E", "9k_trunk2sILi64E", "9k_trunk16I"):
+        ks = {k: v for k, v in opsel_check.SCRATCH.items() if sym in k}
+        assert ks and all(v == 0 for v in ks.values()), {k[-40:]: v for k, v in ks.items() if v}

@@ -18,6 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pinn_for_quantum_wavefunction_surfaces_amd", "csrc")
 
 
+SCRATCH = {}     # kernel symbol -> bytes of scratch per lane (filled by scan)
+
+
 def scan(asm_path):
     cur, hits, tot = None, collections.defaultdict(list), collections.Counter()
     for line in open(asm_path):
@@ -28,6 +31,9 @@ def scan(asm_path):
             tot[cur] += 1
             if re.search(r"op_sel:\[", line):
                 hits[cur].append(line.strip())
+        m = re.match(r"^; ScratchSize: (\d+)", line)
+        if m and cur:
+            SCRATCH[cur] = int(m.group(1))
     return hits, tot
 
 

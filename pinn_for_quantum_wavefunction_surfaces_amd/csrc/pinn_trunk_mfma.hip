@@ -2897,6 +2897,451 @@ hipError_t launch_trunkD_t(const float* theta, __bf16* wpk, const TrunkArgs& A, 
 }
 
 // =====================================================================================
+// k_trunkDx<ACT>: the 4x128 trunk in split-bf16 (fp32-grade: BASELINE config 1), symmetric double pass, full
+// reverse sweep -- k_trunkD's decomposition (8 waves share a 16-point tile, each owning 16 neurons; weights from
+// L2 into registers; saved layer state parked in a per-block region of global memory; gradient accumulators in
+// registers; two waves per SIMD) with every MFMA operand as hi + lo bf16 planes and three MFMAs per product.
+// Two operand planes double every exchange buffer, so only ONE pass of a tile (64 columns) fits the LDS: the tile
+// goes through   forward A (keeps only its output sums)  ->  forward B  ->  tail  ->  reverse B  ->  forward A
+// again  ->  reverse A,   i.e. one extra forward pass (+17 % arithmetic) instead of a second set of buffers.
+// The three stages run as ONE loop body (stage 0: forward A; 1: forward B, tail, reverse B; 2: forward A, reverse
+// A) so the code of a forward and of a reverse pass exists once.  Saved state is fp32 (as in every split-bf16
+// kernel: the adjoint algebra must not be the precision bottleneck): 16 registers per layer, parked for layers 1
+// and 2, kept for layer 3; layer 0 is re-evaluated in the reverse sweep.
+struct TDxCfg {
+    static constexpr int H = 128, L = 4, HT = 8, KC = 4, WAVES = 8, NW = 3;
+    static constexpr int EB1 = KC * NST * 64 * 16;                // one plane of one pass buffer
+    static constexpr int EB = 2 * EB1;                            // hi plane, lo plane
+    static constexpr int NSMALL = 3 * H + NW * H + H + 4;
+    static constexpr int RB = 4 * WAVES, RECF = 12;
+    static constexpr int RBYTES = RB * 16 * RECF * 4;
+    static constexpr size_t OFF_X = 0;                            // [NW] layer-output buffers of the current pass
+    static constexpr size_t OFF_Y = OFF_X + (size_t)NW * EB;
+    static constexpr size_t OFF_SMALL = OFF_Y + EB;
+    static constexpr size_t OFF_S = OFF_SMALL + NSMALL * 4;       // [wave][16 points][pass][Sv, Sl]
+    static constexpr size_t OFF_R = OFF_S + WAVES * 16 * 2 * 2 * 4;
+    static constexpr size_t LDS_BYTES = OFF_R + RBYTES;
+    static constexpr size_t STASH_BLOCK = (size_t)(NW - 1) * WAVES * 4 * 1024;   // bytes per block (one pass at a time)
+    static_assert(LDS_BYTES <= 160 * 1024, "k_trunkDx does not fit the CU's LDS");
+    static_assert(OFF_S % 16 == 0 && OFF_R % 16 == 0, "alignment");
+};
+
+template <int ACT>
+__global__ __launch_bounds__(TDxCfg::WAVES * 64, 2)
+void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, uint4* __restrict__ stash_g, TrunkArgs A)
+{
+    using C = TDxCfg;
+    constexpr int H = C::H, L = C::L, HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB, EB1 = C::EB1, NW = C::NW;
+    using Lay = TrunkLayout<H, L>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    typedef __attribute__((address_space(3))) unsigned char* lds_p;
+    const lds_p lds0 = (lds_p)lds_raw;
+    float* small = reinterpret_cast<float*>(lds_raw + C::OFF_SMALL);
+    float* sW0a = small;
+    float* sW0b = small + H;
+    float* sb0 = small + 2 * H;
+    float* sbl = small + 3 * H;       // b_l at + (l - 1) * H
+    float* swo = small + 3 * H + NW * H;
+    float* sbo = swo + H;
+    float* SB = reinterpret_cast<float*>(lds_raw + C::OFF_S);
+
+    const int lane = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int lane16 = lane * 16;
+    const int own_slot = lane16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
+    const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
+    const int n0 = 16 * part + 4 * g;
+
+    for (int k = threadIdx.x; k < H; k += NT) {
+        sW0a[k] = theta[Lay::W(0) + 2 * k];
+        sW0b[k] = theta[Lay::W(0) + 2 * k + 1];
+        sb0[k] = theta[Lay::b(0) + k];
+#pragma unroll
+        for (int l = 1; l < L; l++) sbl[(l - 1) * H + k] = theta[Lay::b(l) + k];
+        swo[k] = theta[Lay::Wout + k];
+    }
+    if (threadIdx.x == 0) sbo[0] = theta[Lay::bout];
+    __syncthreads();
+    const float bout = sbo[0];
+
+    // A fragments of matrix m = (l - 1) * 2 + dir, plane p (0 hi, 1 lo), of this wave's 16 rows
+    constexpr int WPLANE_B = NW * 2 * H * H * 2;                  // bytes of one packed weight plane
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wpk_g), 0, 2 * WPLANE_B, 0x00020000);
+    const int wvoff = part * KC * 1024 + lane16;
+    auto loadA = [&](int m, bf16x8 (&ah)[KC], bf16x8 (&al)[KC]) {
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            ah[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + kc * 1024, m * H * H * 2, 0));
+            al[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + kc * 1024, WPLANE_B + m * H * H * 2, 0));
+        }
+    };
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(stash_g, 0, (int)(C::STASH_BLOCK * gridDim.x), 0x00020000);
+    const int svoff = ((blockIdx.x * (NW - 1) * C::WAVES + part) * 256 + lane) * 16;
+    auto stash_put = [&](int l, int k, f32x4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, svoff + k * 1024, (l - 1) * C::WAVES * 4096, 0);
+    };
+    auto stash_get = [&](int l, int k) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, svoff + k * 1024, (l - 1) * C::WAVES * 4096, 0));
+    };
+
+    f32x4 wacc[NW][HT], bacc[L], w0acc0 = splat(0.f), w0acc1 = splat(0.f), woacc = splat(0.f);
+#pragma unroll
+    for (int l = 0; l < NW; l++)
+#pragma unroll
+        for (int it = 0; it < HT; it++) wacc[l][it] = splat(0.f);
+#pragma unroll
+    for (int l = 0; l < L; l++) bacc[l] = splat(0.f);
+    float acc_bout = 0.f, acc_pde = 0.f, acc_bc1 = 0.f, acc_bc2 = 0.f;
+    float invN1 = A.invN1, invN2 = A.invN2;
+    if (A.bc_counts) {
+        const long long c1 = A.bc_counts[0], c2 = A.bc_counts[1];
+        invN1 = c1 > 0 ? 1.0f / (float)c1 : 0.0f;
+        invN2 = c2 > 0 ? 1.0f / (float)c2 : 0.0f;
+    }
+    const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
+    const int64_t ntile = (A.n + 15) / 16;
+    const int64_t iters = (ntile + gridDim.x - 1) / gridDim.x;
+
+    constexpr int RB = C::RB, RECF = C::RECF;
+    float* ring = reinterpret_cast<float*>(lds_raw + C::OFF_R);
+    struct PointRec { float x, y, z, R, E, g; unsigned mk; };
+    auto load_rec = [&](int64_t b) {
+        const int64_t tl = (b * RB + 4 * part + g) * gridDim.x + blockIdx.x;
+        int64_t id = tl * 16 + c;
+        id = (tl < ntile && id < A.n) ? id : A.n - 1;
+        PointRec r;
+        r.x = A.x[id]; r.y = A.y[id]; r.z = A.z[id]; r.R = A.R[id]; r.E = A.E[id]; r.g = A.g[id];
+        r.mk = A.mask ? A.mask[id] : 0u;
+        return r;
+    };
+    auto fill_ring = [&](const PointRec& r) {
+        float i0[NST], i1[NST], ri1, ri2;
+        const float rho2 = r.y * r.y + r.z * r.z, rho = __builtin_amdgcn_sqrtf(rho2);
+        orbital_cyl<float>(r.x - r.R, rho2, rho, i0, ri1);
+        orbital_cyl<float>(r.x + r.R, rho2, rho, i1, ri2);
+        float* d = ring + ((4 * part + g) * 16 + c) * RECF;
+        *reinterpret_cast<f32x4*>(d) = f32x4{i0[0], i0[1], i0[2], i0[3]};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{i1[0], i1[1], i1[2], i1[3]};
+        *reinterpret_cast<f32x4*>(d + 8) = f32x4{ri1 + ri2, r.E, r.g, (float)r.mk};
+    };
+    auto put = [&](lds_p eb, int s, f32x4 v) {      // own 4 neurons of stream s: hi plane, lo plane
+        u32x2 ph, pl;
+        split4(v, ph, pl);
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + own_slot + s * 1024) = ph;
+        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + EB1 + own_slot + s * 1024) = pl;
+    };
+    auto bfrag = [&](lds_p eb, int kc, int s) {
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + lane16 + (kc * NST + s) * 1024);
+    };
+    auto trfrag = [&](lds_p eb, int T, int ph) {
+        const lds_p p0 = eb + trl + ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 64));
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    // D[own 16 rows][NST column tiles] += A x B, split operands (hi*hi, hi*lo, lo*hi into the same accumulator); the
+    // hi B fragments of chunk kc+1 are requested before the MFMAs of chunk kc issue
+    auto gemmX = [&](const bf16x8 (&ah)[KC], const bf16x8 (&al)[KC], lds_p eb, f32x4 (&d)[NST]) {
+        bf16x8 xh[2][NST], xl[NST];
+        auto fetch_hi = [&](int kc, bf16x8 (&xx)[NST]) {
+#pragma unroll
+            for (int s = 0; s < NST; s++) xx[s] = bfrag(eb, kc, s);
+        };
+        fetch_hi(0, xh[0]);
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+#pragma unroll
+            for (int s = 0; s < NST; s++) xl[s] = bfrag(eb + EB1, kc, s);
+            if (kc + 1 < KC) fetch_hi(kc + 1, xh[(kc + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc], xh[kc & 1][s], d[s]);
+#pragma unroll
+            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc], xl[s], d[s]);
+#pragma unroll
+            for (int s = 0; s < NST; s++) d[s] = mfma(al[kc], xh[kc & 1][s], d[s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // weight gradient of one layer from one pass: K = 64 columns = 2 steps (stream pairs) x HT column tiles
+    auto wgradX = [&](f32x4 (&wa)[HT], lds_p yb, lds_p xb) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const bf16x8 fyh = trfrag(yb, part, k), fyl = trfrag(yb + EB1, part, k);
+#pragma unroll
+            for (int i0 = 0; i0 < HT; i0 += 2) {
+                bf16x8 fxh[2], fxl[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) { fxh[i] = trfrag(xb, i0 + i, k); fxl[i] = trfrag(xb + EB1, i0 + i, k); }
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    wa[i0 + i] = mfma(fyh, fxh[i], wa[i0 + i]);
+                    wa[i0 + i] = mfma(fyh, fxl[i], wa[i0 + i]);
+                    wa[i0 + i] = mfma(fyl, fxh[i], wa[i0 + i]);
+                }
+            }
+        }
+    };
+    auto ring_in = [&](int slot, float (&inA)[2][NST]) {
+        const float* rp = ring + (slot * 16 + c) * RECF;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+        for (int s = 0; s < NST; s++) { inA[0][s] = r0[s]; inA[1][s] = r1[s]; }
+    };
+    // layer-0 inputs of pass ps: (f1, f2) streams for pass A, (f2, f1) for pass B
+    auto inputs = [&](int slot, int ps, float (&f)[2][NST]) {
+        float inA[2][NST];
+        ring_in(slot, inA);
+#pragma unroll
+        for (int s = 0; s < NST; s++) { f[0][s] = ps ? inA[1][s] : inA[0][s]; f[1][s] = ps ? inA[0][s] : inA[1][s]; }
+    };
+
+    const lds_p YB = lds0 + C::OFF_Y;
+    PointRec nxt = load_rec(0);
+    bf16x8 afh[KC], afl[KC];
+    for (int64_t itx = 0; itx < iters; itx++) {
+        const int64_t tile = itx * gridDim.x + blockIdx.x;
+        const int64_t idx = tile * 16 + c;
+        const bool valid = tile < ntile && idx < A.n;
+        const int slot = (int)(itx % RB);
+        if (slot == 0) {
+            if (itx) __syncthreads();
+            fill_ring(nxt);
+            nxt = load_rec(itx / RB + 1);
+            __syncthreads();
+        }
+        float tNb = 0.f, tlapNb = 0.f;      // adjoints of N and lap N (from the tail), shared by both reverse passes
+#pragma unroll 1
+        for (int stage = 0; stage < 3; stage++) {
+            const int ps = stage == 1 ? 1 : 0;          // stage 0: forward A; 1: forward B, tail, reverse B; 2: forward A, reverse A
+            const bool keep = stage > 0;
+            // ================= forward pass ps =================
+            loadA(0, afh, afl);
+            {
+                float f[2][NST];
+                inputs(slot, ps, f);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW0a + n0), w1 = *reinterpret_cast<const f32x4*>(sW0b + n0);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb0 + n0);
+                const lds_p X0 = lds0 + C::OFF_X;
+                f32x4 a[NST];
+#pragma unroll
+                for (int s = 0; s < NST; s++) a[s] = lin2(w0, f[0][s], w1, f[1][s]);
+                f32x4 s0, s1, s2;
+                act012v<ACT>(a[0] + b0, s0, s1, s2);
+                const f32x4 q = a[1] * a[1] + a[2] * a[2];
+                put(X0, 0, s0);
+                put(X0, 1, s1 * a[1]);
+                put(X0, 2, s1 * a[2]);
+                put(X0, SLP, s1 * a[SLP] + s2 * q);
+            }
+            __syncthreads();
+            f32x4 st3[NST];                 // (h, a_x, a_rho, a_lap) of the last hidden layer of this pass
+#pragma unroll
+            for (int l = 1; l < L; l++) {
+                const lds_p Xin = lds0 + C::OFF_X + (size_t)(l - 1) * EB;
+                const lds_p Xout = lds0 + C::OFF_X + (size_t)l * EB;
+                f32x4 acc[NST];
+                acc[0] = *reinterpret_cast<const f32x4*>(sbl + (l - 1) * H + n0);
+#pragma unroll
+                for (int s = 1; s < NST; s++) acc[s] = splat(0.f);
+                gemmX(afh, afl, Xin, acc);
+                loadA(l < L - 1 ? l * 2 : (L - 2) * 2 + 1, afh, afl);     // next layer forward, or the transposed last layer
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 s0, s1, s2;
+                act012v<ACT>(acc[0], s0, s1, s2);
+                const f32x4 q = acc[1] * acc[1] + acc[2] * acc[2];
+                const f32x4 ol = s1 * acc[SLP] + s2 * q;
+                if (l < L - 1) {
+                    put(Xout, 0, s0);
+                    put(Xout, 1, s1 * acc[1]);
+                    put(Xout, 2, s1 * acc[2]);
+                    put(Xout, SLP, ol);
+                    if (keep) {
+                        stash_put(l, 0, s0);
+#pragma unroll
+                        for (int s = 1; s < NST; s++) stash_put(l, s, acc[s]);
+                    }
+                } else {
+                    const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + n0);
+                    st3[0] = s0;
+#pragma unroll
+                    for (int s = 1; s < NST; s++) st3[s] = acc[s];
+                    const float tot = xg_sum_pair(dot4(wo, s0), dot4(wo, ol));
+                    if ((g & 1) == 0) SB[((part * 16 + c) * 2 + ps) * 2 + (g >> 1)] = tot;
+                }
+                __syncthreads();
+            }
+            if (stage == 0) continue;
+            // ================= tail (once, when both passes' output sums are there) =================
+            if (stage == 1) {
+                float inA[2][NST];
+                ring_in(slot, inA);
+                const f32x4 r2 = *reinterpret_cast<const f32x4*>(ring + (slot * 16 + c) * RECF + 8);
+                const unsigned mkpt = (unsigned)r2[3];
+                const float F = inA[0][0] + A.P * inA[1][0];
+                const float lapF = inA[0][SLP] + A.P * inA[1][SLP];
+                float Sv = 0.f, Sl = 0.f;
+#pragma unroll
+                for (int pp = 0; pp < C::WAVES; pp++) {
+                    Sv += SB[((pp * 16 + c) * 2) * 2] + A.P * SB[((pp * 16 + c) * 2 + 1) * 2];
+                    Sl += SB[((pp * 16 + c) * 2) * 2 + 1] + A.P * SB[((pp * 16 + c) * 2 + 1) * 2 + 1];
+                }
+                Tail<float> t;
+                tail<float>(A.out_scale * Sv + bout, A.out_scale * Sl, r2[2], r2[1], F, lapF, r2[0], A.a, A.b, A.c,
+                            float(mkpt & 1), float((mkpt >> 1) & 1), A.invN, invN1, invN2, valid ? 1.0f : 0.0f, t);
+                if (valid && g == 0 && part == 0) { A.Eb[idx] = t.Eb; A.gb[idx] = t.gb; }
+                acc_pde += lead * t.l_pde;
+                acc_bc1 += lead * t.l_bc1;
+                acc_bc2 += lead * t.l_bc2;
+                acc_bout += lead * t.Nb;
+                tNb = t.Nb; tlapNb = t.lapNb;
+            }
+            // ================= adjoints of the last hidden layer of pass ps -> YB =================
+            {
+                const f32x4 wo = *reinterpret_cast<const f32x4*>(swo + n0);
+                const float pw = ps ? A.P : 1.0f;
+                const float cv = A.out_scale * pw * tNb, cl = A.out_scale * pw * tlapNb;
+                const f32x4 h = st3[0];
+                f32x4 s1, s2, s3;
+                act123v<ACT>(h, s1, s2, s3);
+                const f32x4 q = st3[1] * st3[1] + st3[2] * st3[2];
+                woacc += mul_bcast(h, cv) + mul_bcast(s1 * st3[SLP] + s2 * q, cl);
+                const f32x4 o0 = mul_bcast(wo, cv), ol = mul_bcast(wo, cl);
+                const f32x4 u = 2.0f * s2 * ol;
+                const f32x4 y0 = s1 * o0 + (s2 * st3[SLP] + s3 * q) * ol;
+                bacc[L - 1] += y0;
+                put(YB, 0, y0);
+                put(YB, 1, u * st3[1]);
+                put(YB, 2, u * st3[2]);
+                put(YB, SLP, s1 * ol);
+            }
+            __syncthreads();
+            // ================= reverse steps l = L-1 .. 1 of pass ps =================
+#pragma unroll
+            for (int l = L - 1; l >= 1; l--) {
+                const lds_p Xin = lds0 + C::OFF_X + (size_t)(l - 1) * EB;
+                f32x4 sq[NST];
+                if (l > 1) {
+#pragma unroll
+                    for (int s = 0; s < NST; s++) sq[s] = stash_get(l - 1, s);
+                }
+                wgradX(wacc[l - 1], YB, Xin);
+                f32x4 ob[NST];
+#pragma unroll
+                for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
+                gemmX(afh, afl, YB, ob);
+                if (l > 1) loadA((l - 2) * 2 + 1, afh, afl);      // the transposed matrix of layer l-1
+                __builtin_amdgcn_sched_barrier(0);
+                if (l > 1) {
+                    const f32x4 h = sq[0], a1 = sq[1], a2 = sq[2], al_ = sq[3];
+                    f32x4 s1, s2, s3;
+                    act123v<ACT>(h, s1, s2, s3);
+                    const f32x4 q = a1 * a1 + a2 * a2;
+                    const f32x4 u = 2.0f * s2 * ob[SLP];
+                    const f32x4 y0 = s1 * ob[0] + s2 * (a1 * ob[1] + a2 * ob[2]) + (s2 * al_ + s3 * q) * ob[SLP];
+                    const f32x4 y1 = s1 * ob[1] + u * a1, y2 = s1 * ob[2] + u * a2, y3 = s1 * ob[SLP];
+                    bacc[l - 1] += y0;
+                    __syncthreads();                // every wave has read YB (and X[l-1])
+                    put(YB, 0, y0);
+                    put(YB, 1, y1);
+                    put(YB, 2, y2);
+                    put(YB, SLP, y3);
+                    __syncthreads();
+                } else {
+                    float f[2][NST];
+                    inputs(slot, ps, f);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW0a + n0), w1 = *reinterpret_cast<const f32x4*>(sW0b + n0);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb0 + n0);
+                    f32x4 a[NST];
+#pragma unroll
+                    for (int s = 0; s < NST; s++) a[s] = lin2(w0, f[0][s], w1, f[1][s]);
+                    f32x4 h0, s1, s2, s3;
+                    act012v<ACT>(a[0] + b0, h0, s1, s2);
+                    act123v<ACT>(h0, s1, s2, s3);
+                    const f32x4 q = a[1] * a[1] + a[2] * a[2];
+                    const f32x4 u = 2.0f * s2 * ob[SLP];
+                    f32x4 ab[NST];
+                    ab[SLP] = s1 * ob[SLP];
+                    ab[1] = s1 * ob[1] + u * a[1];
+                    ab[2] = s1 * ob[2] + u * a[2];
+                    ab[0] = s1 * ob[0] + s2 * (a[1] * ob[1] + a[2] * ob[2]) + (s2 * a[SLP] + s3 * q) * ob[SLP];
+                    bacc[0] += ab[0];
+#pragma unroll
+                    for (int s = 0; s < NST; s++) { fmac_bcast(w0acc0, ab[s], f[0][s]); fmac_bcast(w0acc1, ab[s], f[1][s]); }
+                    __syncthreads();                // X[0] and YB are rewritten by the next forward pass
+                }
+            }
+        }
+    }
+    // =========================== block reduction ===========================
+    __syncthreads();
+    constexpr int PT = Lay::size;
+    float* out = A.partial + (size_t)blockIdx.x * A.stride;
+    const float s0 = row16_sum(xg_sum(acc_pde)), s1r = row16_sum(xg_sum(acc_bc1)),
+                s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int l = 0; l < L; l++) bacc[l][r] = row16_sum(bacc[l][r]);
+        w0acc0[r] = row16_sum(w0acc0[r]); w0acc1[r] = row16_sum(w0acc1[r]);
+        woacc[r] = row16_sum(woacc[r]);
+    }
+    float* sc = reinterpret_cast<float*>(lds_raw);
+    if (threadIdx.x < 4) sc[threadIdx.x] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int l = 1; l < L; l++)
+#pragma unroll
+        for (int it = 0; it < HT; it++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nj = q_neuron(16 * part + 4 * g + r), ni = q_neuron(16 * it + c);
+                out[Lay::W(l) + nj * H + ni] = wacc[l - 1][it][r];
+            }
+    if (c == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int nj = n0 + r;
+#pragma unroll
+            for (int l = 0; l < L; l++) out[Lay::b(l) + nj] = bacc[l][r];
+            out[Lay::W(0) + 2 * nj] = w0acc0[r];
+            out[Lay::W(0) + 2 * nj + 1] = w0acc1[r];
+            out[Lay::Wout + nj] = woacc[r];
+        }
+    }
+    for (int w = 0; w < C::WAVES; w++) {
+        if (part == w && lane == 0) { sc[0] += s0; sc[1] += s1r; sc[2] += s2r; sc[3] += s3r; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
+    if (threadIdx.x == 3) out[Lay::bout] = sc[3];
+}
+
+template <int ACT>
+hipError_t launch_trunkDx_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
+{
+    using C1 = MCfg<128, 4>;
+    using C = TDxCfg;
+    const int nfrag = C1::NW * 2 * C1::HT * C1::KC * 64;
+    hipLaunchKernelGGL((k_pack_weights<128, 4, true>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    auto kern = k_trunkDx<ACT>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    uint4* stash = reinterpret_cast<uint4*>(reinterpret_cast<char*>(wpk) + mfma_packed_weight_bytes(128, 4));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::WAVES * 64), C::LDS_BYTES, st, theta, (const __bf16*)wpk, stash, A);
+    return hipGetLastError();
+}
+
+// =====================================================================================
 // R-only nets (E-net 1 -> 32 -> 32 -> 1, gate 1 -> 10 -> 1) in the trunk's transposed layout:
 // a wave owns 16 points; lane (g, c) holds, for point c, neurons 16 jt + 4 g + r of both row
 // tiles.  The 32 x 32 layer (forward, its transpose in the reverse sweep) is three split-bf16
@@ -3646,7 +4091,8 @@ int mfma_blocks_per_cu(int H, int L, bool x3)
 // bytes behind the packed weights for k_trunkD's parked saved state (nblocks = the persistent grid)
 size_t mfma_stash_bytes(int H, int L, bool x3, int nblocks)
 {
-    if (x3 || L != 4) return 0;
+    if (L != 4) return 0;
+    if (x3) return H == 128 ? TDxCfg::STASH_BLOCK * (size_t)nblocks : 0;
     return (H == 128 ? TDCfg<128, 4>::STASH_BLOCK : H == 64 ? TDCfg<64, 4>::STASH_BLOCK : 0) * (size_t)nblocks;
 }
 
@@ -3722,8 +4168,13 @@ bool launch_trunk_mfma_128x4(int act, int npass, int mode, bool x3, int variant,
                              const TrunkArgs& A, int grid, hipStream_t st, hipError_t* err)
 {
     __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
-    if (x3)   // BASELINE config 1 (4x128 fp32-grade): hi plane streamed through LDS by LDS-DMA, lo plane from
-              // L2, one layer-output buffer (XONE)
+    if (x3 && npass == 2 && mode == MODE_BWD && variant != 3) {   // BASELINE config 1 (4x128 fp32-grade): k_trunkDx
+        *err = act == ACT_TANH ? launch_trunkDx_t<ACT_TANH>(theta, wpk, A, grid, st)
+                               : launch_trunkDx_t<ACT_SIGMOID>(theta, wpk, A, grid, st);
+        return true;
+    }
+    if (x3)   // the other modes of 4x128 split-bf16: hi plane streamed through LDS by LDS-DMA, lo plane from L2, one
+              // layer-output buffer (XONE)
         return launch2_HL<128, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (npass == 2 && mode == MODE_BWD && variant != 3) {
         *err = act == ACT_TANH ? launch_trunkD_t<128, 4, ACT_TANH>(theta, wpk, A, grid, st)

@@ -691,7 +691,8 @@ def test_deep_trunk_kernel_ragged_sizes_and_ring_refill(H, n):
 
 
 @pytest.mark.parametrize("H,L,prec", [(16, 2, "f32"), (64, 2, "bf16"), (64, 2, "bf16x3"), (128, 2, "bf16"),
-                                      (64, 4, "bf16"), (128, 4, "bf16"), (64, 2, "bf16-B"), (128, 2, "bf16-B")])
+                                      (64, 4, "bf16"), (128, 4, "bf16"), (64, 2, "bf16-B"), (128, 2, "bf16-B"),
+                                      (128, 4, "bf16x3")])
 def test_bitwise_reproducible_with_co_resident_blocks(H, L, prec):
     """131 072 points = a full persistent grid (two workgroups per CU where the kernel is built for that): four
     calls with the same inputs return the same bits.  Round 2 found k_trunk2<64> differing from run to run in

@@ -3040,27 +3040,24 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 64));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
-    // D[own 16 rows][NST column tiles] += A x B, split operands (hi*hi, hi*lo, lo*hi into the same accumulator); the
-    // hi B fragments of chunk kc+1 are requested before the MFMAs of chunk kc issue
+    // D[own 16 rows][NST column tiles] += A x B, split operands (hi*hi, hi*lo, lo*hi into the same accumulator).  The B
+    // fragments of a k chunk are requested right before its twelve MFMAs: prefetching the next chunk's (16 more
+    // registers) spilled and was 11 % slower; the SIMD's other wave covers the LDS latency
     auto gemmX = [&](const bf16x8 (&ah)[KC], const bf16x8 (&al)[KC], lds_p eb, f32x4 (&d)[NST]) {
-        bf16x8 xh[2][NST], xl[NST];
-        auto fetch_hi = [&](int kc, bf16x8 (&xx)[NST]) {
-#pragma unroll
-            for (int s = 0; s < NST; s++) xx[s] = bfrag(eb, kc, s);
-        };
-        fetch_hi(0, xh[0]);
+        bf16x8 xh[NST], xl[NST];
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) {
 #pragma unroll
+            for (int s = 0; s < NST; s++) xh[s] = bfrag(eb, kc, s);
+#pragma unroll
             for (int s = 0; s < NST; s++) xl[s] = bfrag(eb + EB1, kc, s);
-            if (kc + 1 < KC) fetch_hi(kc + 1, xh[(kc + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc], xh[kc & 1][s], d[s]);
+            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc], xh[s], d[s]);
 #pragma unroll
             for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc], xl[s], d[s]);
 #pragma unroll
-            for (int s = 0; s < NST; s++) d[s] = mfma(al[kc], xh[kc & 1][s], d[s]);
+            for (int s = 0; s < NST; s++) d[s] = mfma(al[kc], xh[s], d[s]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -3146,7 +3143,7 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
 #pragma unroll
                 for (int s = 1; s < NST; s++) acc[s] = splat(0.f);
                 gemmX(afh, afl, Xin, acc);
-                loadA(l < L - 1 ? l * 2 : (L - 2) * 2 + 1, afh, afl);     // next layer forward, or the transposed last layer
+                if (l < L - 1) loadA(l * 2, afh, afl);                    // next layer's forward matrix
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 s0, s1, s2;
                 act012v<ACT>(acc[0], s0, s1, s2);
@@ -3226,13 +3223,14 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
 #pragma unroll
                     for (int s = 0; s < NST; s++) sq[s] = stash_get(l - 1, s);
                 }
+                // this step's transposed matrix: requested here, behind the weight gradient's 48 MFMAs (not a step
+                // earlier: 32 registers less through the elementwise phase, where the pressure peaks)
+                loadA((l - 1) * 2 + 1, afh, afl);
                 wgradX(wacc[l - 1], YB, Xin);
                 f32x4 ob[NST];
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
                 gemmX(afh, afl, YB, ob);
-                if (l > 1) loadA((l - 2) * 2 + 1, afh, afl);      // the transposed matrix of layer l-1
-                __builtin_amdgcn_sched_barrier(0);
                 if (l > 1) {
                     const f32x4 h = sq[0], a1 = sq[1], a2 = sq[2], al_ = sq[3];
                     f32x4 s1, s2, s3;

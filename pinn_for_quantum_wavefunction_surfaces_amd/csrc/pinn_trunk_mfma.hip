@@ -24,7 +24,7 @@
 // k_trunk2      two hidden layers, symmetric double pass, full reverse sweep (the benchmark's shape,
 //   H = 64 and 128, bf16): H/16 waves share a 16-point tile, both passes swept together.
 // k_trunk2s     the same for train.py's single-pass formulation: two tiles per trip.
-// k_trunk2x     k_trunk2 in split-bf16 (2x64).   k_trunkD   deep trunks (L = 4), bf16.
+// k_trunk2x     k_trunk2 in split-bf16 (2x64).   k_trunkD   deep trunks (L = 4), bf16.   k_trunkDx   4x128 in split-bf16.
 // k_trunk_mfma2 every other wide shape and mode (L = 4, single pass, forward-only, frozen trunk,
 //   split-bf16): SPLIT waves share a 16-point tile, each owning 16 or 32 neurons, pass by pass;
 //   layer outputs and adjoints are exchanged through LDS buffers in B-fragment order, which double

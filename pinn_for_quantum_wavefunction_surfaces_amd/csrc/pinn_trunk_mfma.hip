@@ -2965,17 +2965,10 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     __syncthreads();
     const float bout = sbo[0];
 
-    // A fragments of matrix m = (l - 1) * 2 + dir, plane p (0 hi, 1 lo), of this wave's 16 rows
+    // A fragments of matrix m = (l - 1) * 2 + dir of this wave's 16 rows: hi plane, lo plane (one packed plane later)
     constexpr int WPLANE_B = NW * 2 * H * H * 2;                  // bytes of one packed weight plane
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wpk_g), 0, 2 * WPLANE_B, 0x00020000);
     const int wvoff = part * KC * 1024 + lane16;
-    auto loadA = [&](int m, bf16x8 (&ah)[KC], bf16x8 (&al)[KC]) {
-#pragma unroll
-        for (int kc = 0; kc < KC; kc++) {
-            ah[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + kc * 1024, m * H * H * 2, 0));
-            al[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + kc * 1024, WPLANE_B + m * H * H * 2, 0));
-        }
-    };
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(stash_g, 0, (int)(C::STASH_BLOCK * gridDim.x), 0x00020000);
     const int svoff = ((blockIdx.x * (NW - 1) * C::WAVES + part) * 256 + lane) * 16;
     auto stash_put = [&](int l, int k, f32x4 v) {
@@ -3041,9 +3034,15 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
     // D[own 16 rows][NST column tiles] += A x B, split operands (hi*hi, hi*lo, lo*hi into the same accumulator).  The B
-    // fragments of a k chunk are requested right before its twelve MFMAs: prefetching the next chunk's (16 more
-    // registers) spilled and was 11 % slower; the SIMD's other wave covers the LDS latency
-    auto gemmX = [&](const bf16x8 (&ah)[KC], const bf16x8 (&al)[KC], lds_p eb, f32x4 (&d)[NST]) {
+    // fragments of a k chunk are requested right before its twelve MFMAs (prefetching the next chunk's, 16 more
+    // registers, spilled and was 11 % slower; the SIMD's other wave covers the LDS latency); the A fragments (hi and
+    // lo) of matrix m are streamed from L2 two k chunks ahead: 16 registers in flight instead of 32 resident, -6 %
+    auto loadA1 = [&](int m, int kc, bf16x8& ah, bf16x8& al) {
+        ah = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + kc * 1024, m * H * H * 2, 0));
+        al = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + kc * 1024, WPLANE_B + m * H * H * 2, 0));
+    };
+    auto gemmXs = [&](int m, bf16x8 (&ah)[2], bf16x8 (&al)[2], lds_p eb, f32x4 (&d)[NST]) {
+        // ah[0..1], al[0..1] hold chunks 0 and 1 on entry (requested by the caller a phase ahead)
         bf16x8 xh[NST], xl[NST];
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) {
@@ -3053,11 +3052,12 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
             for (int s = 0; s < NST; s++) xl[s] = bfrag(eb + EB1, kc, s);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc], xh[s], d[s]);
+            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc & 1], xh[s], d[s]);
 #pragma unroll
-            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc], xl[s], d[s]);
+            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc & 1], xl[s], d[s]);
 #pragma unroll
-            for (int s = 0; s < NST; s++) d[s] = mfma(al[kc], xh[s], d[s]);
+            for (int s = 0; s < NST; s++) d[s] = mfma(al[kc & 1], xh[s], d[s]);
+            if (kc + 2 < KC) loadA1(m, kc + 2, ah[kc & 1], al[kc & 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -3096,7 +3096,8 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
 
     const lds_p YB = lds0 + C::OFF_Y;
     PointRec nxt = load_rec(0);
-    bf16x8 afh[KC], afl[KC];
+    bf16x8 afh[2], afl[2];
+    auto loadA2 = [&](int m) { loadA1(m, 0, afh[0], afl[0]); loadA1(m, 1, afh[1], afl[1]); };
     for (int64_t itx = 0; itx < iters; itx++) {
         const int64_t tile = itx * gridDim.x + blockIdx.x;
         const int64_t idx = tile * 16 + c;
@@ -3114,7 +3115,7 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
             const int ps = stage == 1 ? 1 : 0;          // stage 0: forward A; 1: forward B, tail, reverse B; 2: forward A, reverse A
             const bool keep = stage > 0;
             // ================= forward pass ps =================
-            loadA(0, afh, afl);
+            loadA2(0);
             {
                 float f[2][NST];
                 inputs(slot, ps, f);
@@ -3142,8 +3143,8 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 acc[0] = *reinterpret_cast<const f32x4*>(sbl + (l - 1) * H + n0);
 #pragma unroll
                 for (int s = 1; s < NST; s++) acc[s] = splat(0.f);
-                gemmX(afh, afl, Xin, acc);
-                if (l < L - 1) loadA(l * 2, afh, afl);                    // next layer's forward matrix
+                gemmXs((l - 1) * 2, afh, afl, Xin, acc);
+                if (l < L - 1) loadA2(l * 2);                             // next layer's forward matrix (first two chunks)
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 s0, s1, s2;
                 act012v<ACT>(acc[0], s0, s1, s2);
@@ -3225,12 +3226,12 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 }
                 // this step's transposed matrix: requested here, behind the weight gradient's 48 MFMAs (not a step
                 // earlier: 32 registers less through the elementwise phase, where the pressure peaks)
-                loadA((l - 1) * 2 + 1, afh, afl);
+                loadA2((l - 1) * 2 + 1);
                 wgradX(wacc[l - 1], YB, Xin);
                 f32x4 ob[NST];
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
-                gemmX(afh, afl, YB, ob);
+                gemmXs((l - 1) * 2 + 1, afh, afl, YB, ob);
                 if (l > 1) {
                     const f32x4 h = sq[0], a1 = sq[1], a2 = sq[2], al_ = sq[3];
                     f32x4 s1, s2, s3;

@@ -302,6 +302,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    xstat = {}
+
     def run(model, arch_name):
         """W untimed + K timed steps of one workload; returns (seconds, trunk kernel ms, losses, points/GPU)"""
         a = ARCHS[arch_name]
@@ -341,7 +343,12 @@ def main():
         barrier()
         dt = plan.max_over_ranks(time.perf_counter() - t0, dev)
         kms = float("nan") if args.graph else tr.h.profile_read(min(args.steps, 1024))
-        return dt, kms, tr.losses(), npts
+        # losses() checks the one-shot exchange's status first: a peer that missed a call's timeout
+        # raises here (and the message of that call was NaN), so no number is printed for such a run
+        losses = tr.losses()
+        xstat["name"] = plan.exchange_name
+        xstat["status"] = "ok" if plan._xchg is not None else "n/a"
+        return dt, kms, losses, npts
 
     def gpu_check(TB):
         """parity numbers observed in THIS run: 8 192 of the benchmark's points and its own initial
@@ -387,6 +394,7 @@ def main():
                 "(max-norm relative errors)"}
 
     dt, trunk_ms, (Ltot, Lpde, Lbc), npts = run(model, args.arch)
+    xprimary = dict(xstat)
     # other workloads ride along as secondary records on ONE GPU only (same K, W): the split-bf16 variant
     # of the primary (fp32-grade parity on the MFMA pipe), BASELINE config 1 (4x128 fp32-grade at 100 000
     # points), the reference architecture on the fp32 parity path, its fine-tune mode, and the 2x128 trunk
@@ -422,7 +430,8 @@ def main():
                        "parallelism": "dp%d" % world,
                        "exchange": ("none" if not use_dist else "one-shot peer-memory all-reduce"
                                     if (args.one_shot or os.environ.get("PINN_ONE_SHOT") == "1") else
-                                    ("gloo (one-GPU rehearsal)" if rehearsal else "RCCL all-reduce"))},
+                                    ("gloo (one-GPU rehearsal)" if rehearsal else "RCCL all-reduce")),
+                       "exchange_status": xprimary.get("status", "n/a")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": TRAFFIC.get(args.arch),
                          "traffic_source": TRAFFIC_SOURCE,

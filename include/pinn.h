@@ -165,14 +165,19 @@ int pinn_profile_read(pinn_handle *h, int ncalls, float *mean_trunk_ms);
  * pinn_xchg_local_handle by any means (the Python layer uses torch.distributed.all_gather_object),
  * and each calls pinn_xchg_connect with all N handles in rank order (its own entry is ignored).
  * Every rank must make the same sequence of pinn_xchg_allreduce calls.  buf: device, 16-byte aligned,
- * n <= max_floats, summed in place.  A peer that does not arrive within 20 s leaves buf untouched and
- * sets a status word that pinn_xchg_status (which synchronises the stream) reports as PINN_ERR_HIP. */
+ * n <= max_floats, summed in place.  The call counter lives in device memory, so a call captured into a
+ * HIP graph advances with every replay like an eager call (all ranks must then replay the same graph).
+ * A peer that does not arrive within the timeout (default 20 s; PINN_XCHG_TIMEOUT_S in the environment at
+ * create, or pinn_xchg_set_timeout before the calls it should apply to) makes the call fill buf with NaN
+ * -- a local-only gradient is never handed back as if it were the sum -- and sets a sticky status word
+ * that pinn_xchg_status (which synchronises the stream) reports as PINN_ERR_HIP. */
 typedef struct pinn_xchg pinn_xchg;
 #define PINN_XCHG_HANDLE_BYTES 64
 int pinn_xchg_create(int device, int rank, int world, int64_t max_floats, pinn_xchg **out);
 int pinn_xchg_local_handle(pinn_xchg *x, void *handle64);
 int pinn_xchg_connect(pinn_xchg *x, const void *handles /* world x 64 bytes, rank order */);
 int pinn_xchg_allreduce(pinn_xchg *x, float *buf, int64_t n, void *stream);
+int pinn_xchg_set_timeout(pinn_xchg *x, double seconds);
 int pinn_xchg_status(pinn_xchg *x, void *stream);
 int pinn_xchg_destroy(pinn_xchg *x);
 const char *pinn_xchg_last_error(const pinn_xchg *x);

@@ -16,7 +16,7 @@ EXPORTS = ["pinn_param_count", "pinn_tensor_count", "pinn_tensor_layout", "pinn_
            "pinn_create", "pinn_destroy", "pinn_last_error", "pinn_sample", "pinn_forward",
            "pinn_residual_fwd_bwd", "pinn_adam", "pinn_profile_enable", "pinn_profile_read",
            "pinn_energy_R", "pinn_xchg_create", "pinn_xchg_local_handle", "pinn_xchg_connect",
-           "pinn_xchg_allreduce", "pinn_xchg_status", "pinn_xchg_destroy", "pinn_xchg_last_error"]
+           "pinn_xchg_allreduce", "pinn_xchg_set_timeout", "pinn_xchg_status", "pinn_xchg_destroy", "pinn_xchg_last_error"]
 
 
 class PinnError(RuntimeError):
@@ -76,6 +76,7 @@ def load_library():
     lib.pinn_xchg_local_handle.argtypes = [vp, C.c_char_p]
     lib.pinn_xchg_connect.argtypes = [vp, C.c_char_p]
     lib.pinn_xchg_allreduce.argtypes = [vp, fp, C.c_int64, vp]
+    lib.pinn_xchg_set_timeout.argtypes = [vp, C.c_double]
     lib.pinn_xchg_status.argtypes = [vp, vp]
     lib.pinn_xchg_destroy.argtypes = [vp]
     lib.pinn_xchg_last_error.restype = C.c_char_p
@@ -218,7 +219,12 @@ class Exchange:
         self._check(self.lib.pinn_xchg_allreduce(self.x, _ptr(buf), buf.numel(), Handle._stream()),
                     "pinn_xchg_allreduce")
 
+    def set_timeout(self, seconds):
+        """how long a call waits for the slowest peer before it gives up (NaN result + status)"""
+        self._check(self.lib.pinn_xchg_set_timeout(self.x, float(seconds)), "pinn_xchg_set_timeout")
+
     def status(self):
+        """synchronises the current stream; raises PinnError if any call so far timed out on a peer"""
         self._check(self.lib.pinn_xchg_status(self.x, Handle._stream()), "pinn_xchg_status")
 
     def close(self):

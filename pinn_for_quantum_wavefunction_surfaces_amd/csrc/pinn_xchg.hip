@@ -7,7 +7,9 @@
 // each rank sums the N slots locally: one hop, two small kernels on the caller's stream, no host
 // involvement.  The reference has nothing to match here (it is single device).
 //
-// Protocol (all device-side, per call; seq = 1, 2, 3, ... identical on every rank):
+// Protocol (all device-side, per call; seq = 1, 2, 3, ... identical on every rank, kept in DEVICE memory:
+// both kernels read state[0] = number of completed calls, the last block of the sum kernel advances it,
+// so a call captured into a HIP graph counts on with every replay exactly like an eager call):
 //   memory of rank p:  recv[2][N][cap] floats  +  flag[2][N] words (one 128-byte line each)
 //   push kernel (N blocks):   block q copies buf -> recv_q[seq&1][me][0..n), system-scope fence, then
 //                             flag_q[seq&1][me] = seq (release)
@@ -41,10 +43,14 @@ struct PeerTable {
     unsigned* flag[kMaxWorld];           // base of each rank's flag[2][N][kFlagStride]
 };
 
+// state[0] calls completed (= seq of the last one), state[1] blocks of the running sum kernel that are
+// done, state[2] 1 after a timed-out wait (sticky)
 __global__ __launch_bounds__(kPushThreads) void k_xchg_push(PeerTable T, const float* __restrict__ buf, int64_t n,
-                                                           int64_t cap, int me, int world, unsigned seq)
+                                                           int64_t cap, int me, int world,
+                                                           const unsigned* __restrict__ state)
 {
     const int q = blockIdx.x;            // destination rank
+    const unsigned seq = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const int par = seq & 1;
     float* dst = T.recv[q] + ((size_t)par * world + me) * cap;
     const int64_t n4 = n / 4;
@@ -61,12 +67,16 @@ __global__ __launch_bounds__(kPushThreads) void k_xchg_push(PeerTable T, const f
 
 __global__ __launch_bounds__(kSumThreads) void k_xchg_sum(const float* __restrict__ recv, const unsigned* flag,
                                                          float* __restrict__ buf, int64_t n, int64_t cap, int world,
-                                                         unsigned seq, unsigned long long max_wait_ticks,
-                                                         int* __restrict__ status)
+                                                         unsigned long long max_wait_ticks, unsigned* state)
 {
-    const int par = seq & 1;
     __shared__ int ok;
+    __shared__ unsigned seq_s;
     if (threadIdx.x == 0) {
+        // every block reads state[0] before it counts itself done, and only the last block to be done
+        // advances it: all blocks of this launch see the same seq
+        const unsigned seq = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        const int par = seq & 1;
+        seq_s = seq;
         int good = 1;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
         for (int q = 0; q < world && good; q++) {
@@ -77,16 +87,33 @@ __global__ __launch_bounds__(kSumThreads) void k_xchg_sum(const float* __restric
             }
         }
         ok = good;
-        if (!good) atomicExch(status, 1);   // a peer never arrived: leave buf untouched, report
+        if (!good) atomicExch(state + 2, 1u);   // a peer never arrived: report, and poison buf below
     }
     __syncthreads();
-    if (!ok) return;
-    __threadfence_system();
-    const float* base = recv + (size_t)par * world * cap;
-    for (int64_t i = (int64_t)blockIdx.x * kSumThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kSumThreads) {
-        float s = __builtin_nontemporal_load(base + i);
-        for (int q = 1; q < world; q++) s += __builtin_nontemporal_load(base + (size_t)q * cap + i);
-        buf[i] = s;
+    const unsigned seq = seq_s;
+    const int par = seq & 1;
+    if (ok) {
+        __threadfence_system();
+        const float* base = recv + (size_t)par * world * cap;
+        for (int64_t i = (int64_t)blockIdx.x * kSumThreads + threadIdx.x; i < n;
+             i += (int64_t)gridDim.x * kSumThreads) {
+            float s = __builtin_nontemporal_load(base + i);
+            for (int q = 1; q < world; q++) s += __builtin_nontemporal_load(base + (size_t)q * cap + i);
+            buf[i] = s;
+        }
+    } else {
+        // no silent local-only gradient: whatever consumes buf (loss terms, Adam) sees NaN
+        for (int64_t i = (int64_t)blockIdx.x * kSumThreads + threadIdx.x; i < n;
+             i += (int64_t)gridDim.x * kSumThreads)
+            buf[i] = __builtin_nanf("");
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(state + 1, 1u) == gridDim.x - 1) {     // last block of this call
+            __hip_atomic_store(state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(state, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -95,12 +122,11 @@ __global__ __launch_bounds__(kSumThreads) void k_xchg_sum(const float* __restric
 struct pinn_xchg {
     int device, rank, world;
     int64_t cap;
-    unsigned seq;
     void* local;                 // own allocation: recv then flags
     size_t recv_bytes, flag_bytes;
     void* mapped[kMaxWorld];     // peers' allocations as mapped here (own: == local)
     PeerTable table;
-    int* status;                 // device word: 1 after a timed-out wait
+    unsigned* state;             // device words: [0] calls completed, [1] sum blocks done, [2] timed out
     bool connected;
     double timeout_s;
     char err[256];
@@ -135,6 +161,10 @@ extern "C" int pinn_xchg_create(int device, int rank, int world, int64_t max_flo
     x->device = device; x->rank = rank; x->world = world;
     x->cap = (max_floats + 63) / 64 * 64;            // slots start on 256-byte boundaries
     x->timeout_s = 20.0;
+    if (const char* t = getenv("PINN_XCHG_TIMEOUT_S")) {
+        const double v = atof(t);
+        if (v > 0) x->timeout_s = v;
+    }
     *out = x;
     XCHK(x, hipSetDevice(device));
     x->recv_bytes = (size_t)2 * world * x->cap * sizeof(float);
@@ -150,8 +180,8 @@ extern "C" int pinn_xchg_create(int device, int rank, int world, int64_t max_flo
         else XCHK(x, hipExtMallocWithFlags(&x->local, bytes, hipDeviceMallocUncached));
     }
     XCHK(x, hipMemset(x->local, 0, x->recv_bytes + x->flag_bytes));
-    XCHK(x, hipMalloc(&x->status, sizeof(int)));
-    XCHK(x, hipMemset(x->status, 0, sizeof(int)));
+    XCHK(x, hipMalloc(&x->state, 4 * sizeof(unsigned)));
+    XCHK(x, hipMemset(x->state, 0, 4 * sizeof(unsigned)));
     XCHK(x, hipDeviceSynchronize());
     snprintf(x->err, sizeof x->err, "ok");
     return PINN_OK;
@@ -194,25 +224,31 @@ extern "C" int pinn_xchg_allreduce(pinn_xchg* x, float* buf, int64_t n, void* st
     if (n < 1 || n > x->cap) return xfail(x, PINN_ERR_CAPACITY, "message longer than max_floats");
     if (((uintptr_t)buf & 15) != 0) return xfail(x, PINN_ERR_ARG, "buf must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const unsigned seq = ++x->seq;
     hipLaunchKernelGGL(k_xchg_push, dim3(x->world), dim3(kPushThreads), 0, st, x->table, (const float*)buf, n, x->cap,
-                       x->rank, x->world, seq);
+                       x->rank, x->world, (const unsigned*)x->state);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xfail(x, PINN_ERR_HIP, "k_xchg_push", e);
     const int blocks = (int)((n + kSumThreads * 4 - 1) / (kSumThreads * 4));
     hipLaunchKernelGGL(k_xchg_sum, dim3(blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks)), dim3(kSumThreads), 0, st,
                        (const float*)x->table.recv[x->rank], (const unsigned*)x->table.flag[x->rank], buf, n, x->cap,
-                       x->world, seq, (unsigned long long)(x->timeout_s * 1e8), x->status);
+                       x->world, (unsigned long long)(x->timeout_s * 1e8), x->state);
     e = hipGetLastError();
     if (e != hipSuccess) return xfail(x, PINN_ERR_HIP, "k_xchg_sum", e);
+    return PINN_OK;
+}
+
+extern "C" int pinn_xchg_set_timeout(pinn_xchg* x, double seconds)
+{
+    if (!x || !(seconds > 0)) return PINN_ERR_ARG;
+    x->timeout_s = seconds;
     return PINN_OK;
 }
 
 extern "C" int pinn_xchg_status(pinn_xchg* x, void* stream)
 {
     if (!x) return PINN_ERR_ARG;
-    int s = 0;
-    XCHK(x, hipMemcpyAsync(&s, x->status, sizeof s, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    unsigned s = 0;
+    XCHK(x, hipMemcpyAsync(&s, x->state + 2, sizeof s, hipMemcpyDeviceToHost, (hipStream_t)stream));
     XCHK(x, hipStreamSynchronize((hipStream_t)stream));
     if (s) return xfail(x, PINN_ERR_HIP, "a peer did not arrive within the exchange timeout");
     return PINN_OK;
@@ -227,7 +263,7 @@ extern "C" int pinn_xchg_destroy(pinn_xchg* x)
         for (int q = 0; q < x->world; q++)
             if (q != x->rank && x->mapped[q]) (void)hipIpcCloseMemHandle(x->mapped[q]);
     if (x->local) (void)hipFree(x->local);
-    if (x->status) (void)hipFree(x->status);
+    if (x->state) (void)hipFree(x->state);
     delete x;
     return PINN_OK;
 }

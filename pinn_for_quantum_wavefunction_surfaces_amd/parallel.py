@@ -17,8 +17,12 @@ one_shot=True (or PINN_ONE_SHOT=1) replaces the all-reduce of the gradient messa
 library's own exchange over peer-mapped memory (include/pinn.h pinn_xchg_*: every rank writes its
 6-205 KB vector into a slot in every peer's memory over the xGMI mesh and sums the N slots in rank
 order -- one hop, two small kernels on the compute stream, bitwise identical sums on all ranks);
-torch.distributed is then only used once, to trade the 64-byte memory handles.  RCCL stays the
-default until the one-shot path has been measured on an 8-GPU node.
+torch.distributed is then only used at setup (to trade the 64-byte memory handles, and one barrier
+before the first call); the boundary-set sizes of reduce_counts travel through the same exchange as
+16-bit pieces in fp32 (exact), so a captured step contains no torch.distributed call at all.  A peer
+that misses the exchange timeout turns the message into NaN and sets a status that check() -- called
+wherever the Trainer synchronises anyway -- raises as PinnError.  RCCL stays the default until the
+one-shot path has been measured on an 8-GPU node.
 """
 import os
 
@@ -52,7 +56,25 @@ class DataParallelPlan:
             dist.all_gather_object(out, mine, group=self.group)
             return out
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        self._xchg = capi.Exchange(idx, self.rank, self.world, max_floats, gather)
+        self._xchg = capi.Exchange(idx, self.rank, self.world, max(int(max_floats), 8), gather)
+        self._cnt_f = torch.zeros(8, device=device, dtype=torch.float32)    # 2 counts x 4 pieces of 16 bits
+        self._shifts = torch.tensor([0, 16, 32, 48], device=device, dtype=torch.int64)
+        if self.world > 1:
+            # every rank has mapped every peer before anybody's first push; also absorbs start-up skew
+            # (library load, first-touch) that would otherwise eat into the first call's timeout
+            dist.barrier(group=self.group)
+
+    def check(self):
+        """Raise PinnError if a one-shot exchange call has timed out on a peer (synchronises the
+        current stream); a no-op on the RCCL/gloo path, where a missing peer blocks instead."""
+        if self._xchg is not None:
+            self._xchg.status()
+
+    @property
+    def exchange_name(self):
+        if not self.collectives:
+            return "none"
+        return "one-shot peer-memory all-reduce" if self._xchg is not None else "all-reduce"
 
     def _sum(self, buf):
         if self._xchg is not None:
@@ -75,7 +97,14 @@ class DataParallelPlan:
 
     def reduce_counts(self, counts):
         """int64[2] BC set sizes: local -> global (in place)."""
-        if self.collectives:
+        if not self.collectives:
+            return counts
+        if self._xchg is not None:
+            # 16-bit pieces as floats: sums over <= 16 ranks stay below 2^24, i.e. exact in fp32
+            self._cnt_f.copy_(torch.bitwise_and(counts[:, None] >> self._shifts, 0xFFFF).reshape(8))
+            self._xchg.allreduce(self._cnt_f)
+            counts.copy_((self._cnt_f.reshape(2, 4).to(torch.int64) << self._shifts).sum(1))
+        else:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
         return counts
 

@@ -121,6 +121,8 @@ class Trainer:
         and return a callable that replays it (bit-identical to eager steps).  Measured: no gain,
         even at 10^4 points the step is bound by per-tile kernel latency, not by launches."""
         self.pipelined = False                      # a graph is bound to one set of buffers
+        # (the one-shot exchange counts its calls in device memory, so it replays correctly; data
+        # parallel, every rank must capture and replay the same step)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -154,7 +156,9 @@ class Trainer:
         self.h.residual_fwd_bwd(self.theta, x, y, z, R, mask, self.n, ham, self._cnt[cur],
                                 self.tmask, self.grad)
         k = int(next_resample or 0)
-        if self.pipelined and k >= 1:               # points of step t + k and their local counts
+        # points of step t + k and their local counts -- unless an earlier step already drew them (with
+        # sc_sampling > 1 the driver hints at the same step twice: at the resampling step and at t+k-1)
+        if self.pipelined and k >= 1 and self._ahead_for != self.t + k:
             self._sample_into(1 - cur, self._cnt_local, None, k)
             # ONE message: [grad | losses | that batch's counts]
             self.plan.reduce_grad_and_counts(self.gbuf, self._cnt_local, self._cnt[1 - cur])
@@ -225,11 +229,14 @@ class Trainer:
         return _State()
 
     def losses(self):
-        """(Ltot, Lpde, Lbc) of the last step as floats (this one does synchronise)."""
+        """(Ltot, Lpde, Lbc) of the last step as floats (this one does synchronise; on the one-shot
+        exchange it is also where a peer that missed the timeout is reported)."""
+        self.plan.check()
         l = self.grad[self.P:].tolist()
         return l[0] + l[1] + l[2], l[0], l[1] + l[2]
 
     def sync_to_model(self, best=False):
+        self.plan.check()
         self.model.load_flat_params(self.best_theta if best else self.theta)
 
 
@@ -272,6 +279,7 @@ def train(params, loadWeights=False, freezeUnits=False, model=None, device="cuda
         tr.h.forward(tr.theta, tr.x[-1:], tr.y[-1:], tr.z[-1:], tr.R[-1:], 1, model.ham(),
                      E=E_h[tt:tt + 1])                                     # poc/main.py:411
     torch.cuda.synchronize()
+    tr.plan.check()
     runtime = time.time() - t0
     hist = hist.cpu().numpy().astype(np.float64)
     history = {"Ltot": hist.sum(1, keepdims=True), "Lbc": hist[:, 1:].sum(1, keepdims=True),

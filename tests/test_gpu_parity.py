@@ -690,7 +690,41 @@ def test_deep_trunk_kernel_ragged_sizes_and_ring_refill(H, n):
         assert abs(out[P:].sum() / ref["Ltot"] - 1) < 5e-2 and rel(out[:P], ref["grad"]) < 5e-2
 
 
-@pytest.mark.parametrize("H,L,prec", [(16, 2, "f32"), (64, 2, "bf16"), (64, 2, "bf16x3"), (128, 2, "bf16"),
+@pytest.mark.parametrize("n", [1, 17, 4113, 300000])
+def test_deep_split_bf16_kernel_ragged_sizes_and_ring_refill(n):
+    """k_trunkDx (4x128 split-bf16, BASELINE config 1) at sizes that leave a tile and a ring batch partly empty and at
+    300 000 points, where every block goes through several ring batches (ring refill, re-use of the parked layer
+    state tile after tile): loss and gradient against the oracle at the fp32-grade bar (small sizes) and against the
+    pass-by-pass kernel (PINN_MFMA_VARIANT=3) to round-off."""
+    H = 128
+    A = O.arch(H=H, L=4, act=1)
+    rng = np.random.default_rng(977 + n)
+    off, sz = O.tensor_layout(A)
+    theta = np.zeros(O.param_count(A))
+    fan = [2, 2] + [H, H] * 3 + [H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    for o, s_, fi in zip(off, sz, fan):
+        theta[o:o + s_] = rng.uniform(-1, 1, s_) / np.sqrt(fi)
+    x, y, z = rng.uniform(-18, 18, (3, n))
+    R = rng.uniform(0.2, 4, n)
+    mask = rng.integers(0, 4, n).astype(np.uint8)
+    f = pkg.model.FORMULATION_A
+    h = capi.Handle(capi.Arch(H, 4, 32, 10, 1, 2, 1.0, capi.PINN_PREC_BF16X3), 0, max(n, 8192))
+    try:
+        os.environ["PINN_MFMA_VARIANT"] = "0"
+        out = run_loss_grad(h, f, theta, x, y, z, R, mask)
+        os.environ["PINN_MFMA_VARIANT"] = "3"
+        old = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    finally:
+        os.environ.pop("PINN_MFMA_VARIANT", None)
+    P = h.P
+    assert np.isfinite(out).all()
+    assert abs(out[P:].sum() / old[P:].sum() - 1) < 2e-5 and rel(out[:P], old[:P]) < 1e-4
+    if n < 10000:
+        ref = O.loss_grad(A, O.ham_A(), theta, x, y, z, R, mask)
+        assert abs(out[P:].sum() / ref["Ltot"] - 1) < 2e-4 and rel(out[:P], ref["grad"]) < 2e-4
+
+
+@pytest.mark.parametrize("H,L,prec", [(16, 2, "f32"), (32, 2, "f32"), (16, 3, "f32"), (64, 2, "bf16"), (64, 2, "bf16x3"), (128, 2, "bf16"),
                                       (64, 4, "bf16"), (128, 4, "bf16"), (64, 2, "bf16-B"), (128, 2, "bf16-B"),
                                       (128, 4, "bf16x3")])
 def test_bitwise_reproducible_with_co_resident_blocks(H, L, prec):
@@ -1294,3 +1328,105 @@ def test_one_shot_exchange_equals_fixed_order_sum(tmp_path, world):
         s.close()
         mp.spawn(_dp_worker, args=(2, port, 6000, 6, str(tmp_path)), nprocs=2, join=True)
         assert np.array_equal(np.load(tmp_path / "rank0.npz")["theta"], th[0])
+
+
+def _xchg_graph_worker(rank, world, port, out_dir):
+    """captured steps on the one-shot path: the exchange's call counter lives in device memory, so
+    every replay is a new call (slot parity, flag value) exactly like an eager one"""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import pinn_for_quantum_wavefunction_surfaces_amd as pk
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        params = pk.set_params()
+        w = torch.tensor(np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))["ionHsym"])
+
+        def make():
+            m = pk.NN_ion(params).to(dev)
+            m.load_flat_params(w)
+            return pk.Trainer(m, params, n_points=6000, lr=8e-3, device=dev,
+                              plan=pk.DataParallelPlan(6000, one_shot=True))
+        a, b = make(), make()
+        for _ in range(9):
+            a.step()
+        replay = b.capture_graph(warmup=3)          # 3 eager steps + 1 captured (not run)
+        for _ in range(6):                          # both slot parities, three times each
+            replay()
+        torch.cuda.synchronize()
+        a.plan.check()
+        b.plan.check()
+        assert int(a.step_count.item()) == int(b.step_count.item()) == 9
+        assert torch.equal(a.theta, b.theta) and torch.equal(a.grad, b.grad), rank
+        # the boundary-set sizes went through the exchange (16-bit pieces): same as the pipelined path's
+        assert torch.equal(a.counts, b.counts)
+        np.save(os.path.join(out_dir, "gtheta%d.npy" % rank), b.theta.cpu().numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_shot_exchange_inside_a_captured_graph(tmp_path):
+    """2 ranks on one GPU, every rank replays its captured step 6 times: same theta as 9 eager
+    one-shot steps, bit for bit, and rank-identical (a host-side call counter baked into the graph
+    would stop waiting for the peers from the second replay on)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_xchg_graph_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / "gtheta0.npy"), np.load(tmp_path / "gtheta1.npy"))
+
+
+def _xchg_timeout_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import pinn_for_quantum_wavefunction_surfaces_amd as pk
+    from pinn_for_quantum_wavefunction_surfaces_amd import capi as cp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        plan = pk.DataParallelPlan(1000, one_shot=True)
+        plan.attach_exchange(dev, 64)
+        buf = torch.ones(64, device=dev)
+        plan.reduce_grad(buf)                       # call 1: everybody arrives
+        torch.cuda.synchronize()
+        plan.check()
+        assert torch.equal(buf.cpu(), torch.full((64,), float(world)))
+        if rank == 0:                               # call 2: the peer never comes
+            plan._xchg.set_timeout(0.5)
+            buf.fill_(1.0)
+            plan.reduce_grad(buf)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(buf).all())     # never a local-only "sum"
+            try:
+                plan.check()
+                raised = False
+            except cp.PinnError as e:
+                raised = "timeout" in str(e)
+            assert raised
+            open(os.path.join(out_dir, "timeout_reported"), "w").write("1")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_shot_exchange_reports_a_missing_peer(tmp_path):
+    """a peer that misses the (here 0.5 s) timeout: the message comes back as NaN and
+    DataParallelPlan.check() -- which Trainer.losses() / sync_to_model() / train() call -- raises"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_xchg_timeout_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "timeout_reported").exists()

@@ -193,3 +193,5 @@ def test_trainer_sequencing_two_ranks_equal_one(tmp_path):
     # the plain path samples once per resampling step; the pipelined one once per hint (+ the first batch
     # and the two steps whose hint was missing or wrong)
     assert int(np.load(tmp_path / "plain_rank0.npz")["nsample"]) == sum(rs for rs, _ in SCHEDULE)
+    # ... and a batch that an earlier hint already drew is not drawn again (steps 1 and 2 both hint at step 3)
+    assert int(np.load(tmp_path / "pipe_rank0.npz")["nsample"]) == 11

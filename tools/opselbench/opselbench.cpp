@@ -15,7 +15,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int MODE>   // 0: operands from an LDS record; 1: operands produced by VALU instructions
+// MFMA = 0 (round 3): the same loop without the two MFMAs -- the regime of the exact-fp32 lane = point kernels of
+// csrc/pinn_kernels.hip (k_trunk for H = 32 / L = 3, the R-net fallbacks), which still contain the op_sel forms.
+template <int MODE, int MFMA = 1>   // MODE 0: operands from an LDS record; 1: operands produced by VALU instructions
 __global__ __launch_bounds__(256) void k_opsel(const float* __restrict__ in, unsigned long long* __restrict__ bad, int iters,
                                                float* __restrict__ sink)
 {
@@ -49,8 +51,10 @@ __global__ __launch_bounds__(256) void k_opsel(const float* __restrict__ in, uns
         const float p[2] = {__builtin_bit_cast(float, (unsigned)pp), __builtin_bit_cast(float, (unsigned)(pp >> 32))};
         const float q[2] = {__builtin_bit_cast(float, (unsigned)qq), __builtin_bit_cast(float, (unsigned)(qq >> 32))};
         // a few MFMAs in between, as in the kernel's surroundings
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+        if (MFMA) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+        }
         float s0, s1, t0, t1;
         asm volatile("v_mul_f32 %0, %1, %2" : "=v"(s0) : "v"(w0), "v"(r[1]));
         asm volatile("v_mul_f32 %0, %1, %2" : "=v"(s1) : "v"(w1), "v"(r[1]));
@@ -85,11 +89,12 @@ int main()
     for (int i = 0; i < 65536; i++) h[i] = (float)rand() / RAND_MAX * 4.f - 2.f;
     hipMemcpy(in, h, 65536 * sizeof(float), hipMemcpyHostToDevice);
     const int iters = 20000;   // < 65536: the four per-lane counters are 16-bit fields
+    for (int mfma = 1; mfma >= 0; mfma--)
     for (int mode = 0; mode < 2; mode++)
         for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu *= 2) {
             // LDS per workgroup sized so that exactly wg_per_cu of them fit a CU's 160 KB
             const size_t ldsb = wg_per_cu == 1 ? 100 * 1024 : wg_per_cu == 2 ? 70 * 1024 : 36 * 1024;
-            auto kern = mode == 0 ? k_opsel<0> : k_opsel<1>;
+            auto kern = mfma ? (mode == 0 ? k_opsel<0, 1> : k_opsel<1, 1>) : (mode == 0 ? k_opsel<0, 0> : k_opsel<1, 0>);
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
             hipMemset(bad, 0, 4 * sizeof(*bad));
             hipMemset(sink, 0, 64);
@@ -99,8 +104,8 @@ int main()
             float ex[16];
             hipMemcpy(nb, bad, sizeof(nb), hipMemcpyDeviceToHost);
             hipMemcpy(ex, sink, 64, hipMemcpyDeviceToHost);
-            printf("operands from %-5s %d workgroup(s) of 4 waves per CU, %.3g products of each kind: mismatches pk_mul.lo %llu pk_mul.hi %llu "
-                   "pk_fma.lo %llu pk_fma.hi %llu (%s)\n", mode == 0 ? "LDS," : "VALU,", wg_per_cu, 256.0 * 256 * wg_per_cu * iters,
+            printf("%s operands from %-5s %d workgroup(s) of 4 waves per CU, %.3g products of each kind: mismatches pk_mul.lo %llu pk_mul.hi %llu "
+                   "pk_fma.lo %llu pk_fma.hi %llu (%s)\n", mfma ? "MFMAs between," : "no MFMA,      ", mode == 0 ? "LDS," : "VALU,", wg_per_cu, 256.0 * 256 * wg_per_cu * iters,
                    nb[0], nb[1], nb[2], nb[3], hipGetErrorString(e));
             if (nb[0] + nb[1] + nb[2] + nb[3])
                 printf("    first: w = (%.9g, %.9g) x = (%.9g, %.9g): pk_mul (%.9g, %.9g) scalar (%.9g, %.9g); pk_fma (%.9g, %.9g) scalar (%.9g, %.9g)\n",

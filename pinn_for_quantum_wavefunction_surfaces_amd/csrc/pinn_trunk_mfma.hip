@@ -2757,8 +2757,14 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                     for (int ps = 0; ps < 2; ps++) { sq[ps][0] = stash_get(l - 1, 2 * ps); sq[ps][1] = stash_get(l - 1, 2 * ps + 1); }
                 }
             }
-            wgrad(wacc[l - 1], YB, Xin);
-            u32x2 yp[2][NST];               // adjoints of layer l-1, packed: written to YB once every wave has read it
+            // Adjoint buffers rotate: step l reads the adjoints of layer l from Ysrc and writes those of layer l-1
+            // to Ydst.  Only the first reverse step has no free buffer (it writes back into YB, behind a barrier that
+            // says every wave has read it); from the second step on the layer-output buffer X[l] that the step
+            // before consumed (and YB, alternately) is free, so the write needs no barrier in front of it.
+            const lds_p Ysrc = (l >= L - 2 || ((L - 2 - l) & 1) == 0) ? YB : lds0 + C::OFF_X + (size_t)(l + 1) * 2 * EB;
+            const lds_p Ydst = (l - 1 >= L - 2 || ((L - 1 - l) & 1) == 0) ? YB : lds0 + C::OFF_X + (size_t)l * 2 * EB;
+            wgrad(wacc[l - 1], Ysrc, Xin);
+            u32x2 yp[2][NST];               // adjoints of layer l-1, packed
             float inA[2][NST];
             f32x4 w0, w1, b0;
             if (l == 1) {                   // layer 0 is re-evaluated from the point record
@@ -2772,7 +2778,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 f32x4 ob[NST];
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
-                gemmP(afr, YB + ps * EB, ob);
+                gemmP(afr, Ysrc + ps * EB, ob);
                 if (ps == 1) {
                     // next A fragments: the transposed matrix of layer l-1, or layer 1 forward for the next tile
                     loadA(l > 1 ? (l - 2) * 2 + 1 : 0, afr);
@@ -2817,15 +2823,15 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                     for (int s = 0; s < NST; s++) { fmac_bcast(w0acc0, ab[s], inA[ps][s]); fmac_bcast(w0acc1, ab[s], inA[1 - ps][s]); }
                 }
             }
-            __syncthreads();                    // every wave has read YB (and X[l-1])
             if (l > 1) {
+                if (Ydst == Ysrc) __syncthreads();      // (first reverse step) every wave has read it
 #pragma unroll
                 for (int ps = 0; ps < 2; ps++)
 #pragma unroll
                     for (int s = 0; s < NST; s++)
-                        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(YB + ps * EB + own_slot + s * 1024) = yp[ps][s];
-                __syncthreads();
+                        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(Ydst + ps * EB + own_slot + s * 1024) = yp[ps][s];
             }
+            __syncthreads();                    // adjoints of layer l-1 are there; every wave has read Ysrc and X[l-1]
         }
     }
     // =========================== block reduction ===========================
@@ -3227,11 +3233,15 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 // this step's transposed matrix: requested here, behind the weight gradient's 48 MFMAs (not a step
                 // earlier: 32 registers less through the elementwise phase, where the pressure peaks)
                 loadA2((l - 1) * 2 + 1);
-                wgradX(wacc[l - 1], YB, Xin);
+                // adjoint buffers rotate as in k_trunkD: the first reverse step writes back into YB (two barriers),
+                // the second into the layer-output buffer X[2] the first one consumed (one barrier)
+                const lds_p Ysrc = (l >= L - 2) ? YB : lds0 + C::OFF_X + (size_t)(l + 1) * EB;
+                const lds_p Ydst = (l - 1 >= L - 2) ? YB : lds0 + C::OFF_X + (size_t)l * EB;
+                wgradX(wacc[l - 1], Ysrc, Xin);
                 f32x4 ob[NST];
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
-                gemmXs((l - 1) * 2 + 1, afh, afl, YB, ob);
+                gemmXs((l - 1) * 2 + 1, afh, afl, Ysrc, ob);
                 if (l > 1) {
                     const f32x4 h = sq[0], a1 = sq[1], a2 = sq[2], al_ = sq[3];
                     f32x4 s1, s2, s3;
@@ -3241,12 +3251,12 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                     const f32x4 y0 = s1 * ob[0] + s2 * (a1 * ob[1] + a2 * ob[2]) + (s2 * al_ + s3 * q) * ob[SLP];
                     const f32x4 y1 = s1 * ob[1] + u * a1, y2 = s1 * ob[2] + u * a2, y3 = s1 * ob[SLP];
                     bacc[l - 1] += y0;
-                    __syncthreads();                // every wave has read YB (and X[l-1])
-                    put(YB, 0, y0);
-                    put(YB, 1, y1);
-                    put(YB, 2, y2);
-                    put(YB, SLP, y3);
-                    __syncthreads();
+                    if (Ydst == Ysrc) __syncthreads();      // (first reverse step) every wave has read YB
+                    put(Ydst, 0, y0);
+                    put(Ydst, 1, y1);
+                    put(Ydst, 2, y2);
+                    put(Ydst, SLP, y3);
+                    __syncthreads();                // also: every wave has read Ysrc and X[l-1]
                 } else {
                     float f[2][NST];
                     inputs(slot, ps, f);

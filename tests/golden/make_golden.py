@@ -14,6 +14,9 @@ What is produced:
   g1_weights.npz   both checkpoints as flat fp64 vectors (state_dict order)
   g2_formA_*.npz   NN_ion (poc/main.py) on a fixed batch: psi,E,lap,Hpsi,res,losses,grads
                    (tanh64 / tanh16: the same module with its `sig` handle set to nn.Tanh())
+                   (deep128 / deep16: NN_ion with Lin_H3(, Lin_H4) added the way the reference's own
+                   commented-out line poc/main.py:302 does -- only `base` is overridden; forward,
+                   LossFunctions, lapl and the third-order autograd are the reference's)
   g3_formB.npz     train.py formulation on a fixed batch (its own statements, its `d`)
   g4_adam_*.npz    10 torch.optim.Adam steps on stored batches (full and frozen trunk)
   g5_energy.npz    poc/energy_R_ion.pkl table (parsed opcode-by-opcode, never unpickled)
@@ -193,7 +196,43 @@ def gen_form_A(ns):
     m16 = NN_ion(params)
     m16.sig = torch.nn.Tanh()
     out["tanh16"] = eval_form_A(ns, m16, xs, ys, zs, Rs)
+    # more than two hidden layers (BASELINE config 1 is "4x128"): the reference's trunk has two, with a
+    # third commented out (`# fi_r = self.Lin_H3(fi_r); fi_r = self.sig(fi_r)`, poc/main.py:302).  The
+    # subclass below re-enables exactly that pattern for L layers and changes nothing else, so psi, the
+    # Laplacian, the residual, the losses and every gradient still come from the reference's own
+    # forward / lapl / hamiltonian / LossFunctions and torch's autograd.
+    class DeepIon(NN_ion):
+        def __init__(self, params, H, HE, HG, L):
+            super().__init__(params, H, HE, HG)
+            self.n_layers = L
+            for k in range(3, L + 1):
+                setattr(self, "Lin_H%d" % k, torch.nn.Linear(H, H, bias=True))
+
+        def base(self, fi_r1, fi_r2):
+            fi_r = torch.cat((fi_r1, fi_r2), 1)
+            for k in range(1, self.n_layers + 1):
+                fi_r = self.sig(getattr(self, "Lin_H%d" % k)(fi_r))
+            return fi_r
+
+    def deep_order(model, vec_of):
+        keys = ["Lin_H%d" % k for k in range(1, model.n_layers + 1)] + STATE_KEYS[2:]
+        return np.concatenate([vec_of(k + s) for k in keys for s in (".weight", ".bias")])
+
+    for tag, seed, H, L, act, n in (("deep128", 23, 128, 4, torch.nn.Tanh(), 768),
+                                    ("deep16", 29, 16, 3, None, 1024)):
+        torch.manual_seed(seed)
+        m = DeepIon(params, H, 32, 10, L)
+        if act is not None:
+            m.sig = act
+        d = eval_form_A(ns, m, xs[:n], ys[:n], zs[:n], Rs[:n])
+        sd, named = m.state_dict(), dict(m.named_parameters())
+        d["theta"] = deep_order(m, lambda k: sd[k].detach().numpy().ravel())
+        d["grad"] = deep_order(m, lambda k: named[k].grad.detach().numpy().ravel())
+        d["L"] = L
+        out[tag] = d
     for tag, dct in out.items():
+        if len(sys.argv) > 2 and tag not in sys.argv[2:]:
+            continue
         np.savez_compressed(os.path.join(OUT, "g2_formA_%s.npz" % tag), **dct)
         print("g2_formA_%s: Ltot=%.6e |grad|=%.3e" % (tag, dct["Ltot"],
                                                       np.linalg.norm(dct["grad"])))

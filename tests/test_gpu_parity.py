@@ -122,6 +122,51 @@ def test_formulation_B_matches_train_py(golden_dir):
     assert rel(out[:h.P], g["grad"]) < 1e-4
 
 
+def test_three_layer_trunk_matches_reference(golden_dir):
+    """L = 3 pinned to the reference: NN_ion with its commented-out third hidden layer (poc/main.py:302)
+    enabled (make_golden.py: only `base` is overridden), sigmoid, 16/32/10 widths, on the fp32 path"""
+    g = np.load(os.path.join(golden_dir, "g2_formA_deep16.npz"))
+    arch, f = make(dict(L=3))
+    h = capi.Handle(arch, 0, 4096)
+    psi, E, lap, res = run_forward(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"])
+    assert rel(psi, g["psi"]) < 1e-5 and rel(E, g["E"]) < 1e-5
+    assert rel(lap, g["lap"]) < 1e-5 and rel(res, g["res"]) < 2e-5
+    out = run_loss_grad(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"], g["mask"])
+    P = h.P
+    assert abs(out[P:].sum() / g["Ltot"] - 1) < 1e-4 and rel(out[:P], g["grad"]) < 1e-4
+    off, sz = capi.tensor_layout(arch)
+    for o, s_ in zip(off, sz):
+        ref = g["grad"][o:o + s_]
+        assert np.max(np.abs(out[o:o + s_] - ref)) < 2e-4 * max(np.max(np.abs(ref)), 1e-3 * np.max(np.abs(g["grad"])))
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_4x128_trunk_matches_reference(golden_dir, prec):
+    """BASELINE config 1's shape (4x128, tanh) pinned to the reference: NN_ion with hidden layers 3 and 4
+    enabled the way its own commented-out line poc/main.py:302 does, its unchanged forward / lapl /
+    LossFunctions / autograd (make_golden.py, g2 deep128).  split-bf16 (k_trunkDx, the "fp32" of config 1)
+    at the fp32-grade bar, plain bf16 (k_trunkD) at the bf16 bar; every tensor's gradient separately."""
+    g = np.load(os.path.join(golden_dir, "g2_formA_deep128.npz"))
+    f = pkg.model.FORMULATION_A
+    pr = capi.PINN_PREC_BF16X3 if prec == "bf16x3" else capi.PINN_PREC_BF16
+    arch = capi.Arch(128, 4, 32, 10, 1, 2, 1.0, pr)
+    h = capi.Handle(arch, 0, 4096)
+    psi, E, lap, res = run_forward(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"])
+    out = run_loss_grad(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"], g["mask"])
+    P = h.P
+    errs = dict(psi=rel(psi, g["psi"]), E=rel(E, g["E"]), lap=rel(lap, g["lap"]), res=rel(res, g["res"]),
+                loss=abs(out[P:].sum() / g["Ltot"] - 1), grad=rel(out[:P], g["grad"]))
+    terr = _tensor_errors(arch, 4, out[:P], g["grad"])
+    print("4x128 %s vs reference:" % prec, {k: "%.2e" % v for k, v in {**errs, **terr}.items()})
+    assert errs["E"] < 1e-5
+    if prec == "bf16x3":
+        assert errs["psi"] < 1e-5 and errs["lap"] < 1e-5 and errs["res"] < 5e-5
+        assert errs["loss"] < 2e-4 and errs["grad"] < 2e-4 and max(terr.values()) < 4e-4, terr
+    else:
+        assert errs["psi"] < 1e-2 and errs["lap"] < 1e-2 and errs["res"] < 2e-2
+        assert errs["loss"] < 3e-2 and errs["grad"] < 3e-2 and max(terr.values()) < 6e-2, terr
+
+
 def test_three_layer_tanh_small_Rnet_matches_oracle():
     """build extensions (L = 3, tanh, HE = 16, HG = 8): oracle only, no reference vector exists"""
     arch, f = make(dict(L=3, HE=16, HG=8, act=1))

@@ -15,10 +15,15 @@ from oracle import oracle as O
 
 TOL = 1e-12
 ARCHS = dict(ionHsym=(16, 32, 10), fineTune=(16, 32, 10), rand16=(16, 32, 10),
-             rand64=(64, 32, 10), rand32=(32, 16, 8), tanh64=(64, 32, 10), tanh16=(16, 32, 10))
+             rand64=(64, 32, 10), rand32=(32, 16, 8), tanh64=(64, 32, 10), tanh16=(16, 32, 10),
+             deep128=(128, 32, 10), deep16=(16, 32, 10))
 # tanh64 / tanh16: the reference's NN_ion with its activation handle `sig` (poc/main.py:231) set to
 # nn.Tanh() -- BASELINE's "2x64 tanh" workload pinned to the reference's own forward and autograd
-ACT = dict(tanh64=1, tanh16=1)
+ACT = dict(tanh64=1, tanh16=1, deep128=1)
+# deep128 (4x128 tanh: the shape of BASELINE config 1) / deep16 (3x16 sigmoid): NN_ion with Lin_H3(, Lin_H4)
+# enabled the way the reference's own commented-out line poc/main.py:302 does -- everything else (forward,
+# lapl, hamiltonian, LossFunctions, third-order autograd) is the reference's: pins the oracle's L > 2 adjoint
+DEPTH = dict(deep128=4, deep16=3)
 
 
 def rel(a, b):
@@ -29,7 +34,7 @@ def rel(a, b):
 def test_formulation_A_matches_reference_autograd(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, "g2_formA_%s.npz" % tag))
     H, HE, HG = ARCHS[tag]
-    A, Hm = O.arch(H=H, HE=HE, HG=HG, act=ACT.get(tag, 0)), O.ham_A()
+    A, Hm = O.arch(H=H, L=DEPTH.get(tag, 2), HE=HE, HG=HG, act=ACT.get(tag, 0)), O.ham_A()
     assert O.param_count(A) == g["theta"].size
     f = O.forward(A, Hm, g["theta"], g["x"], g["y"], g["z"], g["R"])
     assert rel(f["psi"], g["psi"]) < TOL

@@ -229,6 +229,24 @@ __device__ __forceinline__ void ring_pairs(unsigned addr, float (&in)[2][NST])
     in[1][2] = __builtin_bit_cast(float, (unsigned)p6); in[1][3] = __builtin_bit_cast(float, (unsigned)p7);
 }
 
+// The same eight values as SPLAT pairs (x, x): ds_read2_b32 with both offsets on the wanted dword.  A packed
+// instruction then takes the pair as it is -- no op_sel form of either kind, and none of the v_mov_b32 with which
+// hipcc otherwise builds (x, x) pairs for part of the broadcasts (24 per tile in k_trunk2 with ring_pairs).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ring_splats(unsigned addr, f32x2 (&in)[2][NST])
+{
+    static_assert(NST == 4, "eight stream values per record");
+    asm volatile("ds_read2_b32 %0, %8 offset0:0 offset1:0\n\tds_read2_b32 %1, %8 offset0:1 offset1:1\n\t"
+                 "ds_read2_b32 %2, %8 offset0:2 offset1:2\n\tds_read2_b32 %3, %8 offset0:3 offset1:3\n\t"
+                 "ds_read2_b32 %4, %8 offset0:4 offset1:4\n\tds_read2_b32 %5, %8 offset0:5 offset1:5\n\t"
+                 "ds_read2_b32 %6, %8 offset0:6 offset1:6\n\tds_read2_b32 %7, %8 offset0:7 offset1:7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(in[0][0]), "=&v"(in[0][1]), "=&v"(in[0][2]), "=&v"(in[0][3]),
+                   "=&v"(in[1][0]), "=&v"(in[1][1]), "=&v"(in[1][2]), "=&v"(in[1][3])
+                 : "v"(addr) : "memory");
+}
+__device__ __forceinline__ f32x4 bc4(f32x2 p) { return f32x4{p[0], p[1], p[0], p[1]}; }   // p = (x, x)
+
 // hipcc's hazard recognizer does not look into inline assembly: the operands of these helpers must not be results
 // of MFMA instructions (the callers pass weights, orbital values and results of ordinary VALU arithmetic); each is ONE
 // asm block opened by a wait state, because an operand may be the result of the transcendental instruction right
@@ -1341,26 +1359,26 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         const lds_p XB = lds0 + C::OFF_X + (size_t)(C::XSETS == 2 ? xset : 0) * 2 * EB;   // [pass] at + ps * EB
         const lds_p YB = lds0 + C::OFF_Y;
         // ================= P1: inputs and layer 0 of both passes =================
-        float inA[2][NST];
+        f32x2 inA[2][NST];      // splat pairs (x, x)
         float Usum, Ept, gpt;
         unsigned mkpt;
         {
             const float* rp = ring + ((int)(itx % RB) * 16 + c) * RECF;
             const f32x4 r2 = *reinterpret_cast<const f32x4*>(rp + 8);
-            ring_pairs((unsigned)(uintptr_t)(lds0 + C::OFF_R) + (unsigned)((((int)(itx % RB) * 16 + c) * RECF) * 4), inA);
+            ring_splats((unsigned)(uintptr_t)(lds0 + C::OFF_R) + (unsigned)((((int)(itx % RB) * 16 + c) * RECF) * 4), inA);
             Usum = r2[0]; Ept = r2[1]; gpt = r2[2]; mkpt = (unsigned)r2[3];
         }
-        const float F = inA[0][0] + A.P * inA[1][0];
-        const float lapF = inA[0][SLP] + A.P * inA[1][SLP];
+        const float F = inA[0][0][0] + A.P * inA[1][0][0];
+        const float lapF = inA[0][SLP][0] + A.P * inA[1][SLP][0];
         f32x4 h0[2];            // layer-0 activations of the own neurons, pass A / pass B
         f32x4 sv[2][NST];       // (h, a_x, a_rho, a_lap) of layer 1
 #pragma unroll
         for (int ps = 0; ps < 2; ps++) {
             f32x4 a[NST];
 #pragma unroll
-            for (int s = 1; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
+            for (int s = 1; s < NST; s++) a[s] = w0 * bc4(inA[ps][s]) + w1 * bc4(inA[1 - ps][s]);
             f32x4 s0, s1, s2;
-            act012v_scaled<ACT>(w0e * inA[ps][0] + w1e * inA[1 - ps][0] + b0e, s0, s1, s2);
+            act012v_scaled<ACT>(w0e * bc4(inA[ps][0]) + w1e * bc4(inA[1 - ps][0]) + b0e, s0, s1, s2);
             const f32x4 q = a[1] * a[1] + a[2] * a[2];
             h0[ps] = s0;
             put(XB + ps * EB, 0, s0);
@@ -1470,7 +1488,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             for (int ps = 0; ps < 2; ps++) {
                 f32x4 a[NST];
 #pragma unroll
-                for (int s = 1; s < NST; s++) a[s] = w0 * inA[ps][s] + w1 * inA[1 - ps][s];
+                for (int s = 1; s < NST; s++) a[s] = w0 * bc4(inA[ps][s]) + w1 * bc4(inA[1 - ps][s]);
                 f32x4 s1, s2, s3;
                 act123v<ACT>(h0[ps], s1, s2, s3);
                 const f32x4 q = a[1] * a[1] + a[2] * a[2];
@@ -1482,7 +1500,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 ab[0] = s1 * ob[ps][0] + s2 * (a[1] * ob[ps][1] + a[2] * ob[ps][2]) + (s2 * a[SLP] + s3 * q) * ob[ps][SLP];
                 bacc0 += ab[0];
 #pragma unroll
-                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * inA[ps][s]; w0acc1 += ab[s] * inA[1 - ps][s]; }
+                for (int s = 0; s < NST; s++) { w0acc0 += ab[s] * bc4(inA[ps][s]); w0acc1 += ab[s] * bc4(inA[1 - ps][s]); }
             }
         }
         if (C::XSETS == 1) __syncthreads();   // one set of layer-output buffers: P1 of the next tile overwrites it
@@ -2757,14 +2775,8 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                     for (int ps = 0; ps < 2; ps++) { sq[ps][0] = stash_get(l - 1, 2 * ps); sq[ps][1] = stash_get(l - 1, 2 * ps + 1); }
                 }
             }
-            // Adjoint buffers rotate: step l reads the adjoints of layer l from Ysrc and writes those of layer l-1
-            // to Ydst.  Only the first reverse step has no free buffer (it writes back into YB, behind a barrier that
-            // says every wave has read it); from the second step on the layer-output buffer X[l] that the step
-            // before consumed (and YB, alternately) is free, so the write needs no barrier in front of it.
-            const lds_p Ysrc = (l >= L - 2 || ((L - 2 - l) & 1) == 0) ? YB : lds0 + C::OFF_X + (size_t)(l + 1) * 2 * EB;
-            const lds_p Ydst = (l - 1 >= L - 2 || ((L - 1 - l) & 1) == 0) ? YB : lds0 + C::OFF_X + (size_t)l * 2 * EB;
-            wgrad(wacc[l - 1], Ysrc, Xin);
-            u32x2 yp[2][NST];               // adjoints of layer l-1, packed
+            wgrad(wacc[l - 1], YB, Xin);
+            u32x2 yp[2][NST];               // adjoints of layer l-1, packed: written to YB once every wave has read it
             float inA[2][NST];
             f32x4 w0, w1, b0;
             if (l == 1) {                   // layer 0 is re-evaluated from the point record
@@ -2778,7 +2790,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 f32x4 ob[NST];
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
-                gemmP(afr, Ysrc + ps * EB, ob);
+                gemmP(afr, YB + ps * EB, ob);
                 if (ps == 1) {
                     // next A fragments: the transposed matrix of layer l-1, or layer 1 forward for the next tile
                     loadA(l > 1 ? (l - 2) * 2 + 1 : 0, afr);
@@ -2823,15 +2835,15 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                     for (int s = 0; s < NST; s++) { fmac_bcast(w0acc0, ab[s], inA[ps][s]); fmac_bcast(w0acc1, ab[s], inA[1 - ps][s]); }
                 }
             }
+            __syncthreads();                    // every wave has read YB (and X[l-1])
             if (l > 1) {
-                if (Ydst == Ysrc) __syncthreads();      // (first reverse step) every wave has read it
 #pragma unroll
                 for (int ps = 0; ps < 2; ps++)
 #pragma unroll
                     for (int s = 0; s < NST; s++)
-                        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(Ydst + ps * EB + own_slot + s * 1024) = yp[ps][s];
+                        *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(YB + ps * EB + own_slot + s * 1024) = yp[ps][s];
+                __syncthreads();
             }
-            __syncthreads();                    // adjoints of layer l-1 are there; every wave has read Ysrc and X[l-1]
         }
     }
     // =========================== block reduction ===========================
@@ -3233,15 +3245,11 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 // this step's transposed matrix: requested here, behind the weight gradient's 48 MFMAs (not a step
                 // earlier: 32 registers less through the elementwise phase, where the pressure peaks)
                 loadA2((l - 1) * 2 + 1);
-                // adjoint buffers rotate as in k_trunkD: the first reverse step writes back into YB (two barriers),
-                // the second into the layer-output buffer X[2] the first one consumed (one barrier)
-                const lds_p Ysrc = (l >= L - 2) ? YB : lds0 + C::OFF_X + (size_t)(l + 1) * EB;
-                const lds_p Ydst = (l - 1 >= L - 2) ? YB : lds0 + C::OFF_X + (size_t)l * EB;
-                wgradX(wacc[l - 1], Ysrc, Xin);
+                wgradX(wacc[l - 1], YB, Xin);
                 f32x4 ob[NST];
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
-                gemmXs((l - 1) * 2 + 1, afh, afl, Ysrc, ob);
+                gemmXs((l - 1) * 2 + 1, afh, afl, YB, ob);
                 if (l > 1) {
                     const f32x4 h = sq[0], a1 = sq[1], a2 = sq[2], al_ = sq[3];
                     f32x4 s1, s2, s3;
@@ -3251,12 +3259,12 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                     const f32x4 y0 = s1 * ob[0] + s2 * (a1 * ob[1] + a2 * ob[2]) + (s2 * al_ + s3 * q) * ob[SLP];
                     const f32x4 y1 = s1 * ob[1] + u * a1, y2 = s1 * ob[2] + u * a2, y3 = s1 * ob[SLP];
                     bacc[l - 1] += y0;
-                    if (Ydst == Ysrc) __syncthreads();      // (first reverse step) every wave has read YB
-                    put(Ydst, 0, y0);
-                    put(Ydst, 1, y1);
-                    put(Ydst, 2, y2);
-                    put(Ydst, SLP, y3);
-                    __syncthreads();                // also: every wave has read Ysrc and X[l-1]
+                    __syncthreads();                // every wave has read YB (and X[l-1])
+                    put(YB, 0, y0);
+                    put(YB, 1, y1);
+                    put(YB, 2, y2);
+                    put(YB, SLP, y3);
+                    __syncthreads();
                 } else {
                     float f[2][NST];
                     inputs(slot, ps, f);

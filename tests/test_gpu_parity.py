@@ -140,31 +140,64 @@ def test_three_layer_trunk_matches_reference(golden_dir):
         assert np.max(np.abs(out[o:o + s_] - ref)) < 2e-4 * max(np.max(np.abs(ref)), 1e-3 * np.max(np.abs(g["grad"])))
 
 
+def _round_bf16_pieces(a, pieces):
+    """a rounded to the sum of `pieces` bf16 numbers (1: bf16 operands, 2: the split-bf16 kernels' hi + lo)"""
+    t = torch.tensor(a, dtype=torch.float32)
+    acc, r = torch.zeros_like(t), t.clone()
+    for _ in range(pieces):
+        p_ = r.to(torch.bfloat16).to(torch.float32)
+        acc += p_
+        r = r - p_
+    return acc.double().numpy()
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
 def test_4x128_trunk_matches_reference(golden_dir, prec):
     """BASELINE config 1's shape (4x128, tanh) pinned to the reference: NN_ion with hidden layers 3 and 4
     enabled the way its own commented-out line poc/main.py:302 does, its unchanged forward / lapl /
     LossFunctions / autograd (make_golden.py, g2 deep128).  split-bf16 (k_trunkDx, the "fp32" of config 1)
-    at the fp32-grade bar, plain bf16 (k_trunkD) at the bf16 bar; every tensor's gradient separately."""
+    at the fp32-grade bar, plain bf16 (k_trunkD) at the bf16 bar.
+    Forward quantities and the loss: on the whole fixture, hand-placed points next to the nuclei included.
+    Gradient: (a) on the fixture without those 12 points at the path's usual bar, every tensor separately
+    (against the oracle, which this same fixture pins to the reference at 1e-12 for L = 4); (b) on the whole
+    fixture, where the 12 points (|res| up to 8.4 against a median of 0.016) contribute large terms that
+    cancel most of the rest -- the gradient of THIS batch is ill-conditioned: merely rounding the three dense
+    weight matrices to the kernels' operand precision moves it by 3.2e-4 (16 mantissa bits) / 0.16 (bf16)
+    in the fp64 oracle -- the error is held to 8 x that measured sensitivity (observed 4.5 x / 1.5 x, the same
+    on the two independent kernels of each precision)."""
     g = np.load(os.path.join(golden_dir, "g2_formA_deep128.npz"))
     f = pkg.model.FORMULATION_A
-    pr = capi.PINN_PREC_BF16X3 if prec == "bf16x3" else capi.PINN_PREC_BF16
-    arch = capi.Arch(128, 4, 32, 10, 1, 2, 1.0, pr)
+    x3 = prec == "bf16x3"
+    arch = capi.Arch(128, 4, 32, 10, 1, 2, 1.0, capi.PINN_PREC_BF16X3 if x3 else capi.PINN_PREC_BF16)
     h = capi.Handle(arch, 0, 4096)
-    psi, E, lap, res = run_forward(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"])
-    out = run_loss_grad(h, f, g["theta"], g["x"], g["y"], g["z"], g["R"], g["mask"])
     P = h.P
+    A, Hm = O.arch(H=128, L=4, act=1), O.ham_A()
+    pts = lambda sl: [g[k][sl] for k in ("x", "y", "z", "R")]
+    psi, E, lap, res = run_forward(h, f, g["theta"], *pts(slice(None)))
+    out = run_loss_grad(h, f, g["theta"], *pts(slice(None)), g["mask"])
     errs = dict(psi=rel(psi, g["psi"]), E=rel(E, g["E"]), lap=rel(lap, g["lap"]), res=rel(res, g["res"]),
                 loss=abs(out[P:].sum() / g["Ltot"] - 1), grad=rel(out[:P], g["grad"]))
-    terr = _tensor_errors(arch, 4, out[:P], g["grad"])
-    print("4x128 %s vs reference:" % prec, {k: "%.2e" % v for k, v in {**errs, **terr}.items()})
+    # (b) conditioning of this batch's gradient, measured with the oracle
+    off, sz = O.tensor_layout(A)
+    th_r = g["theta"].copy()
+    for t in (2, 4, 6):
+        th_r[off[t]:off[t] + sz[t]] = _round_bf16_pieces(g["theta"][off[t]:off[t] + sz[t]], 2 if x3 else 1)
+    sens = rel(O.loss_grad(A, Hm, th_r, *pts(slice(None)), g["mask"])["grad"], g["grad"])
+    # (a) without the hand-placed points
+    sl = slice(12, None)
+    ref = O.loss_grad(A, Hm, g["theta"], *pts(sl), g["mask"][sl])
+    out2 = run_loss_grad(h, f, g["theta"], *pts(sl), g["mask"][sl])
+    errs["grad_regular"] = rel(out2[:P], ref["grad"])
+    terr = _tensor_errors(arch, 4, out2[:P], ref["grad"])
+    print("4x128 %s vs reference:" % prec, {k: "%.2e" % v for k, v in {**errs, **terr}.items()}, "sensitivity %.2e" % sens)
     assert errs["E"] < 1e-5
-    if prec == "bf16x3":
-        assert errs["psi"] < 1e-5 and errs["lap"] < 1e-5 and errs["res"] < 5e-5
-        assert errs["loss"] < 2e-4 and errs["grad"] < 2e-4 and max(terr.values()) < 4e-4, terr
+    if x3:
+        assert errs["psi"] < 1e-5 and errs["lap"] < 1e-5 and errs["res"] < 5e-5 and errs["loss"] < 2e-4
+        assert errs["grad_regular"] < 2e-4 and max(terr.values()) < 4e-4, terr
     else:
-        assert errs["psi"] < 1e-2 and errs["lap"] < 1e-2 and errs["res"] < 2e-2
-        assert errs["loss"] < 3e-2 and errs["grad"] < 3e-2 and max(terr.values()) < 6e-2, terr
+        assert errs["psi"] < 1e-2 and errs["lap"] < 1e-2 and errs["res"] < 2e-2 and errs["loss"] < 3e-2
+        assert errs["grad_regular"] < 3e-2 and max(terr.values()) < 6e-2, terr
+    assert errs["grad"] < 8 * sens, (errs["grad"], sens)
 
 
 def test_three_layer_tanh_small_Rnet_matches_oracle():

@@ -18,6 +18,7 @@ What is produced:
                    commented-out line poc/main.py:302 does -- only `base` is overridden; forward,
                    LossFunctions, lapl and the third-order autograd are the reference's)
   g3_formB.npz     train.py formulation on a fixed batch (its own statements, its `d`)
+  g3_formB_tanh64.npz  the same statements with nh = 64 and `torch.sigmoid` resolving to tanh (BASELINE config 0)
   g4_adam_*.npz    10 torch.optim.Adam steps on stored batches (full and frozen trunk)
   g5_energy.npz    poc/energy_R_ion.pkl table (parsed opcode-by-opcode, never unpickled)
                    + Wind-1965 table from poc/main.py:exactE
@@ -254,16 +255,29 @@ def flat_to_state_order(tensors):
     return np.concatenate(parts)
 
 
-def gen_form_B():
+class _TanhTorch:
+    """stands in for the name `torch` inside train.py's loss statements: `torch.sigmoid` (the only activation
+    train.py:45-51 names) resolves to torch.tanh, every other attribute is torch's own"""
+    sigmoid = staticmethod(torch.tanh)
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+
+def gen_form_B(tanh64=False):
+    """tanh64: BASELINE config 0's "2x64 tanh MLP, train.py reference" -- train.py's own statements
+    (train.py:41-57, verbatim, at run time) with nh = 64 and `torch.sigmoid` resolving to tanh"""
     ns, loss_code, _ = load_train_parts()
-    torch.manual_seed(12345)                      # train.py:75
+    torch.manual_seed(4321 if tanh64 else 12345)  # train.py:75
     ns["dtype"] = torch.double                    # train.py:76
-    nh, ne, nl = 16, 32, 10                       # train.py:85-87
+    nh, ne, nl = (64 if tanh64 else 16), 32, 10   # train.py:85-87
     shapes = [(2, nh), (nh,), (nh, nh), (nh,), (nh, 1), (1,), (1, nl), (nl,), (nl, 1), (1,),
               (1, ne), (ne,), (ne, ne), (ne,), (ne, 1), (1,)]
     tensors = [ns["ini"](*s) for s in shapes]     # train.py:88-103 (same call order)
-    x, y, z, R = fixed_batch(2048, 4242, 3.0)
+    x, y, z, R = fixed_batch(1024 if tanh64 else 2048, 4243 if tanh64 else 4242, 3.0)
     env = dict(ns)
+    if tanh64:
+        env["torch"] = _TanhTorch()
     env.update(dict(zip(FLAT_NAMES, tensors)))
     env["x"], env["y"], env["z"] = as_col(x, True), as_col(y, True), as_col(z, True)
     env["R"] = as_col(R)
@@ -276,11 +290,11 @@ def gen_form_B():
     mask = ((r1sq >= 17.5 ** 2).astype(np.uint8) + 2 * (r2sq >= 17.5 ** 2).astype(np.uint8))
     d = lambda t: t.detach().numpy().ravel().copy()
     np.savez_compressed(
-        os.path.join(OUT, "g3_formB.npz"), x=x, y=y, z=z, R=R, mask=mask,
+        os.path.join(OUT, "g3_formB_tanh64.npz" if tanh64 else "g3_formB.npz"), x=x, y=y, z=z, R=R, mask=mask,
         theta=flat_to_state_order(tensors), psi=d(env["psi"]), E=d(env["e"]),
         res=d(env["res"]), Ltot=float(env["Ltot"]), Lpde=float(env["Lpde"]),
         Lbc=float(env["Lbc"]), grad=flat_to_state_order(grads))
-    print("g3_formB: Ltot=%.6e" % float(env["Ltot"]))
+    print("g3_formB%s: Ltot=%.6e" % ("_tanh64" if tanh64 else "", float(env["Ltot"])))
 
 
 # --------------------------------------------------------------------- Adam
@@ -452,7 +466,7 @@ def main():
     torch.set_num_threads(4)
     ns = load_main_defs()
     only = sys.argv[1] if len(sys.argv) > 1 else "g"
-    jobs = [("g1", gen_weights, ()), ("g2", gen_form_A, (ns,)), ("g3", gen_form_B, ()),
+    jobs = [("g1", gen_weights, ()), ("g2", gen_form_A, (ns,)), ("g3", gen_form_B, ()), ("g3", gen_form_B, (True,)),
             ("g4", gen_adam, (ns,)), ("g5", gen_energy, (ns,)), ("g6", gen_modelbin, ()),
             ("g7", gen_force, (ns,))]
     for name, fn, args in jobs:

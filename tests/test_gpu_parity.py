@@ -583,6 +583,33 @@ def test_benchmarked_2x64_tanh_instance_matches_reference(golden_dir, prec):
     assert np.array_equal(out, run_loss_grad(h, f, theta, x, y, z, R, mask))
 
 
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_train_py_formulation_2x64_tanh_matches_reference(golden_dir, prec):
+    """BASELINE config 0's network under train.py's own formulation: train.py:41-57 run verbatim with nh = 64 and
+    `torch.sigmoid` resolving to tanh (make_golden.py, g3_formB_tanh64; single pass, output 2h, coefficients
+    (1, 1, 1)) against the bf16 kernel of that formulation (k_trunk2s) and the split-bf16 path"""
+    g = np.load(os.path.join(golden_dir, "g3_formB_tanh64.npz"))
+    f = pkg.model.FORMULATION_B
+    arch = capi.Arch(64, 2, 32, 10, 1, 1, 2.0, capi.PINN_PREC_BF16 if prec == "bf16" else capi.PINN_PREC_BF16X3)
+    h = capi.Handle(arch, 0, 4096)
+    P = h.P
+    theta, x, y, z, R, mask = [g[k] for k in ("theta", "x", "y", "z", "R", "mask")]
+    psi, E, lap, res = run_forward(h, f, theta, x, y, z, R)
+    out = run_loss_grad(h, f, theta, x, y, z, R, mask)
+    errs = dict(psi=rel(psi, g["psi"]), E=rel(E, g["E"]), res=rel(res, g["res"]),
+                loss=abs(out[P:].sum() / g["Ltot"] - 1), grad=rel(out[:P], g["grad"]))
+    terr = _tensor_errors(arch, 2, out[:P], g["grad"])
+    print("train.py formulation 2x64 tanh %s vs reference:" % prec, {k: "%.2e" % v for k, v in {**errs, **terr}.items()})
+    assert errs["E"] < 1e-5
+    if prec == "bf16":
+        terr = {k: v for k, v in terr.items() if not k.startswith(("WG", "bG"))}   # (see the symmetric test above)
+        assert errs["psi"] < 1e-2 and errs["res"] < 2e-2 and errs["loss"] < 3e-2 and errs["grad"] < 3e-2
+        assert max(terr.values()) < 6e-2, terr
+    else:
+        assert errs["psi"] < 1e-5 and errs["res"] < 5e-5 and errs["loss"] < 2e-4 and errs["grad"] < 2e-4
+        assert max(terr.values()) < 4e-4, terr
+
+
 def test_benchmarked_instance_at_full_size_shards_add_up_and_match_oracle():
     """BASELINE config 2 at its real size: 1 000 000 points through the bf16 2x64 tanh kernel on its
     full persistent grid (every other MFMA test stays at <= 4096 points = a few blocks).

@@ -50,9 +50,14 @@ def test_formulation_A_matches_reference_autograd(golden_dir, tag):
     assert rel(lg["grad"], g["grad"]) < TOL
 
 
-def test_formulation_B_matches_train_py(golden_dir):
-    g = np.load(os.path.join(golden_dir, "g3_formB.npz"))
-    A, Hm = O.arch(n_pass=1, out_scale=2.0), O.ham_B()
+@pytest.mark.parametrize("tag", ["", "_tanh64"])
+def test_formulation_B_matches_train_py(golden_dir, tag):
+    """train.py:41-57 run verbatim by make_golden.py; "_tanh64": the same statements with nh = 64 and
+    `torch.sigmoid` resolving to tanh -- BASELINE config 0's "2x64 tanh MLP,
+    train.py reference" line"""
+    g = np.load(os.path.join(golden_dir, "g3_formB%s.npz" % tag))
+    A = O.arch(H=64, act=1, n_pass=1, out_scale=2.0) if tag else O.arch(n_pass=1, out_scale=2.0)
+    Hm = O.ham_B()
     f = O.forward(A, Hm, g["theta"], g["x"], g["y"], g["z"], g["R"])
     assert rel(f["psi"], g["psi"]) < TOL
     assert rel(f["E"], g["E"]) < TOL

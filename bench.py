@@ -123,13 +123,14 @@ ARCHS["wide4x128x3"] = dict(ARCHS["wide4x128"], precision="bf16x3", dtype="bf16x
                                   "(split-bf16 MFMA trunk: hi+lo operands, 3 MFMAs per product, fp32 accumulate "
                                   "and elementwise), 100 000 points/step, seeded random init")
 # HBM bytes per launch of each workload's trunk kernel from this round's rocprofv3 PMC passes (FETCH_SIZE x 2 --
-# the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r02_default_bench.md).  4x128 bf16
+# the gfx950 correction for coalesced streams -- plus WRITE_SIZE; profiles/r03_default_bench.md: unchanged since round 2,
+# same grids and layouts).  4x128 bf16
 # (k_trunkD<128>): 6.8 GB, nearly all of it the saved layer state the kernel parks in global memory and reads back
 # (64 KB per tile and block, rewritten every tile); the 4x128 split-bf16 kernel (k_trunkDx, 100 000 points): 1.4 GB, its
 # parked fp32 state of two passes plus 64 B/lane of spills.
-TRAFFIC = {"wide64": 71.7e6, "wide64x3": 44.7e6, "ref16": 34.1e6, "ref16ft": 34.7e6, "wide128": 84.3e6,
-           "wide4x128x3": 1422e6, "wide4x64": 88.7e6, "wide4x128": 6820e6}
-TRAFFIC_SOURCE = "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r02_default_bench.md"
+TRAFFIC = {"wide64": 71.7e6, "wide64x3": 44.2e6, "ref16": 34.1e6, "ref16ft": 34.7e6, "wide128": 84.3e6,
+           "wide4x128x3": 1309e6, "wide4x64": 88.7e6, "wide4x128": 6827e6, "wide64B": 71.7e6}
+TRAFFIC_SOURCE = "rocprofv3 PMC FETCH_SIZE*2+WRITE_SIZE per launch, profiles/r03_default_bench.md"
 DEFAULT_ARCH = "wide64"
 
 

@@ -795,6 +795,10 @@ __global__ __launch_bounds__(1024) void k_reduce(const float* __restrict__ partT
     }
 }
 
+// Several blocks (one per 1024 parameters, at most kAdamMaxBlocks): every block reads step_count and best_loss before
+// it takes a ticket, and the block that takes the LAST ticket writes them back -- so no block can see the
+// incremented counter (one block looping over P = 51 233 parameters took 40 us at 4x128).
+constexpr int kAdamMaxBlocks = 64;
 __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
                                                const float* __restrict__ grad,
                                                float* __restrict__ m, float* __restrict__ v,
@@ -803,10 +807,11 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
                                                const uint8_t* __restrict__ tensor_of,
                                                uint64_t trainable_mask,
                                                float* __restrict__ best_theta,
-                                               float* __restrict__ best_loss)
+                                               float* __restrict__ best_loss,
+                                               unsigned* __restrict__ ticket)
 {
     // the bias corrections are formed in double and rounded once, as torch does for fp32 tensors -- by ONE
-    // thread (two double pow() per thread were most of this kernel's 10 us), handed out through LDS
+    // thread per block (two double pow() per thread were most of this kernel's 10 us), handed out through LDS
     __shared__ float sh_step_size, sh_inv_bc2s;
     __shared__ int sh_step, sh_better;
     if (threadIdx.x == 0) {
@@ -818,14 +823,14 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
         sh_step = step0;
         sh_better = best_loss != nullptr && (grad[P] + grad[P + 1] + grad[P + 2]) < *best_loss;
     }
-    __syncthreads();  // thread 0 has read step_count / best_loss before anything is written
+    __syncthreads();  // thread 0 has read step_count / best_loss before this block writes anything or takes its ticket
     const int step = sh_step;
     const float ltot = grad[P] + grad[P + 1] + grad[P + 2];
     const bool better = sh_better != 0;
     const float step_size = sh_step_size, inv_bc2s = sh_inv_bc2s;
     const float b1 = (float)b1d, b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
     const float eps = (float)epsd;
-    for (int k = threadIdx.x; k < P; k += blockDim.x) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < P; k += gridDim.x * blockDim.x) {
         const float th = theta[k];
         if (better && best_theta) best_theta[k] = th;  // train.py:58-60: params the loss was taken at
         if (!((trainable_mask >> tensor_of[k]) & 1)) continue;
@@ -838,8 +843,11 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
         theta[k] = th - step_size * (mk / denom);
     }
     if (threadIdx.x == 0) {
-        *step_count = step;
-        if (better) *best_loss = ltot;
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {   // every block has read step_count / best_loss by now
+            *ticket = 0;                                 // for the next call
+            *step_count = step;
+            if (better) *best_loss = ltot;
+        }
     }
 }
 
@@ -1009,7 +1017,7 @@ struct pinn_handle {
     float *partT, *partR;   // per-block partials
     void* wpk;              // packed bf16 weights (MFMA path)
     float* thT;             // theta with forward matrices input-major (k_prep_theta)
-    unsigned long long* samp; // k_sample: per-block partial counts [2 * 256] + ticket
+    unsigned long long* samp; // k_sample: per-block partial counts [2 * 256] + its ticket; + k_adam's ticket
     uint8_t* tensor_of;     // [P] tensor index of each parameter
     uint64_t trunk_tensors; // bits of the trunk tensors
     int prof_slots;          // 0 = off
@@ -1292,8 +1300,8 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     HIPCHK(h, hipMalloc(&h->partR, sizeof(float) * (size_t)h->nbR * h->strideR));
     HIPCHK(h, hipMalloc(&h->tensor_of, h->P));
     HIPCHK(h, hipMalloc(&h->thT, sizeof(float) * h->P));
-    HIPCHK(h, hipMalloc(&h->samp, sizeof(unsigned long long) * (2 * kSampleMaxBlocks + 1)));
-    HIPCHK(h, hipMemset(h->samp, 0, sizeof(unsigned long long) * (2 * kSampleMaxBlocks + 1)));
+    HIPCHK(h, hipMalloc(&h->samp, sizeof(unsigned long long) * (2 * kSampleMaxBlocks + 2)));   // + k_adam's ticket
+    HIPCHK(h, hipMemset(h->samp, 0, sizeof(unsigned long long) * (2 * kSampleMaxBlocks + 2)));
     if (arch->precision != PINN_PREC_F32)
         HIPCHK(h, hipMalloc(&h->wpk, mfma_packed_weight_bytes(arch->H, arch->L) +
                                          mfma_stash_bytes(arch->H, arch->L, arch->precision == PINN_PREC_BF16X3, h->nbT)));
@@ -1490,9 +1498,11 @@ extern "C" int pinn_adam(pinn_handle* h, float* theta, const float* grad, float*
 {
     if (!h) return PINN_ERR_ARG;
     if (!theta || !grad || !m || !v || !step_count) return fail(h, PINN_ERR_ARG, "null pointer");
-    hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, (hipStream_t)stream, theta, grad, m, v,
-                       step_count, h->P, lr, beta1, beta2, eps, h->tensor_of, trainable_mask,
-                       best_theta, best_loss);
+    const int blocks = (h->P + 1023) / 1024;
+    hipLaunchKernelGGL(k_adam, dim3(blocks < kAdamMaxBlocks ? blocks : kAdamMaxBlocks), dim3(1024), 0,
+                       (hipStream_t)stream, theta, grad, m, v, step_count, h->P, lr, beta1, beta2, eps,
+                       h->tensor_of, trainable_mask, best_theta, best_loss,
+                       reinterpret_cast<unsigned*>(h->samp + 2 * kSampleMaxBlocks + 1));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_adam", e);
     return PINN_OK;

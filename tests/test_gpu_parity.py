@@ -670,6 +670,66 @@ def test_benchmarked_instance_at_full_size_shards_add_up_and_match_oracle():
     assert rel(first[:P].double().cpu().numpy(), ref["grad"]) < 3e-2
 
 
+def test_config_1_at_full_size_shards_add_up_and_match_oracle():
+    """BASELINE config 1 at its real size: 100 000 points through the 4x128 split-bf16 kernel (k_trunkDx) on its full
+    persistent grid (25 trips per block: ring batches, the parked layer state re-used tile after tile).
+    Size-independent properties: per-point outputs of the big launch equal those of 4 launches over its 25 000-point
+    shards bit for bit; [grad | losses] of the big launch equals the sum of the shard launches to fp32 round-off; a
+    1 024-point sample of the per-point outputs and the gradient of the first 2 048 points agree with the fp64 oracle
+    (pinned to the reference for this depth by g2 deep128) at the fp32-grade bar."""
+    n, nsh = 100000, 4
+    f = pkg.model.FORMULATION_A
+    arch = capi.Arch(128, 4, 32, 10, 1, f["n_pass"], f["out_scale"], capi.PINN_PREC_BF16X3)
+    A = O.arch(H=128, L=4, act=1)
+    rng = np.random.default_rng(2027)
+    off, sz = O.tensor_layout(A)
+    theta = np.zeros(O.param_count(A))
+    fan = [2, 2] + [128, 128] * 3 + [128, 128, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    for o, s_, fi in zip(off, sz, fan):
+        theta[o:o + s_] = rng.uniform(-1, 1, s_) / np.sqrt(fi)
+    h = capi.Handle(arch, 0, n)
+    x, y, z, R = [torch.empty(n, device=DEV) for _ in range(4)]
+    mask = torch.empty(n, device=DEV, dtype=torch.uint8)
+    counts = torch.zeros(2, device=DEV, dtype=torch.int64)
+    h.sample(101, 0, 0, n, 18.0, 0.2, 4.0, 0.005, 17.5, x, y, z, R, mask, counts)
+    th = dev32(theta)
+    n1, n2 = [int(c) for c in counts.tolist()]
+    ham = ham_of(f, n, n1, n2)
+    big = torch.empty(h.P + 3, device=DEV)
+    h.residual_fwd_bwd(th, x, y, z, R, mask, n, ham, None, (1 << 63) - 1, big)
+    outs = [torch.empty(n, device=DEV) for _ in range(4)]
+    h.forward(th, x, y, z, R, n, ham_of(f), *outs)
+    tot = torch.zeros(h.P + 3, device=DEV, dtype=torch.float64)
+    part = torch.empty(h.P + 3, device=DEV)
+    m = n // nsh
+    for k in range(nsh):
+        sl = slice(k * m, (k + 1) * m)
+        h.residual_fwd_bwd(th, x[sl], y[sl], z[sl], R[sl], mask[sl], m, ham, None, (1 << 63) - 1, part)
+        tot += part.double()
+        o2 = [torch.empty(m, device=DEV) for _ in range(4)]
+        h.forward(th, x[sl], y[sl], z[sl], R[sl], m, ham_of(f), *o2)
+        for a, b in zip(outs, o2):
+            assert torch.equal(a[sl], b), k
+    m2 = 2048
+    sl = slice(0, m2)
+    first = torch.empty(h.P + 3, device=DEV)
+    h.residual_fwd_bwd(th, x[sl], y[sl], z[sl], R[sl], mask[sl], m2, ham, None, (1 << 63) - 1, first)
+    torch.cuda.synchronize()
+    big64, tot = big.double().cpu().numpy(), tot.cpu().numpy()
+    P = h.P
+    assert np.isfinite(big64).all()
+    assert rel(big64[:P], tot[:P]) < 2e-5 and abs(big64[P:].sum() / tot[P:].sum() - 1) < 2e-5
+    idx = rng.choice(n, 1024, replace=False)
+    xs, ys, zs, Rs = [t[idx].cpu().numpy().astype(np.float64) for t in (x, y, z, R)]
+    fw = O.forward(A, O.ham_A(), theta, xs, ys, zs, Rs)
+    psi, E, lap, res = [o[idx].cpu().numpy().astype(np.float64) for o in outs]
+    assert rel(psi, fw["psi"]) < 1e-5 and rel(E, fw["E"]) < 1e-5 and rel(lap, fw["lap"]) < 1e-5
+    assert rel(res, fw["res"]) < 5e-5
+    ref = O.loss_grad(A, O.ham_A(), theta, *[t[sl].cpu().numpy().astype(np.float64) for t in (x, y, z, R)],
+                      mask[sl].cpu().numpy(), invN=1.0 / n, invN1=1.0 / n1, invN2=1.0 / n2)
+    assert rel(first[:P].double().cpu().numpy(), ref["grad"]) < 2e-4
+
+
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("n", [1, 17, 255, 257, 4113])
 def test_merged_pass_kernels_ragged_sizes(n, prec):

@@ -117,6 +117,17 @@ int pinn_forward(pinn_handle *h, const float *theta, const float *x, const float
 int pinn_energy_R(pinn_handle *h, const float *theta, const float *R, int64_t n, float *E,
                   float *dE, float *d2E, void *stream);
 
+/* Nested composite-Simpson quadrature of a product of two grid functions (integra3d, poc/main.py:179-186, as
+ * energy_from_psi / dEdR_int use it, poc/main.py:438-464,639-676):
+ *   *out = sum_ijk wx[i] wy[j] wz[k] u[(i*ny + j)*nz + k] * v[(i*ny + j)*nz + k]
+ * with u, v the fp32 per-point outputs of pinn_forward on the grid (v == NULL: u squared), the weights the fp64
+ * weight vectors of the 1-D rule along each axis, accumulation in fp64, a fixed summation order (bitwise
+ * reproducible).  scratch: nx doubles of device memory (caller-owned, like everything else); out: one device
+ * double.  Replaces the reference's round trip of psi and H psi to the host and scipy's simps over Python lists. */
+int pinn_quadrature3d(pinn_handle *h, const float *u, const float *v, const double *wx, const double *wy,
+                      const double *wz, int64_t nx, int64_t ny, int64_t nz, double *scratch, double *out,
+                      void *stream);
+
 /* Replaces LossFunctions + Ltot.backward() (poc/main.py:341-355,403;
  * train.py:41-57,71): one fused pass computing the loss terms and d(Ltot)/d(theta).
  * out (P+3 floats): gradient, then invN*sum res^2, invN1*sum_{bc1} psi^2,

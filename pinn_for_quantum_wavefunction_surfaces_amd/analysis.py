@@ -17,37 +17,63 @@ from .model import NN_ion
 
 
 def simpson_weights(x):
-    """w with simpson(f, x=x) == w @ f for every f (the rule is linear in f)."""
+    """w with simpson(f, x=x) == w @ f for every f (the rule is linear in f): one call on the identity."""
     from scipy.integrate import simpson
     x = np.asarray(x, dtype=np.float64)
-    eye = np.eye(x.size)
-    return np.array([simpson(eye[i], x=x) for i in range(x.size)])
+    return np.asarray(simpson(np.eye(x.size), x=x, axis=1), dtype=np.float64)
+
+
+_GRID_CACHE = {}
 
 
 def _grid(params, n_test, device):
-    """linear grid of sampling(..., linearSampling=True) (poc/main.py:133-140,442-449)."""
-    ax = [torch.linspace(params[k + "L"], params[k + "R"], n_test, dtype=torch.float64) for k in "xyz"]
-    xg, yg, zg = torch.meshgrid(*ax, indexing="ij")
-    return ax, [t.reshape(-1).to(device=device, dtype=torch.float32) for t in (xg, yg, zg)]
+    """linear grid of sampling(..., linearSampling=True) (poc/main.py:133-140,442-449), built on `device`;
+    the axes, the three Simpson weight vectors (fp64) and the flattened fp32 coordinates are cached per
+    (box, n_test, device): calculate_E_R asks for the same grid 39 times."""
+    key = (tuple(float(params[k + s]) for k in "xyz" for s in "LR"), int(n_test), str(device))
+    hit = _GRID_CACHE.get(key)
+    if hit is None:
+        ax = [torch.linspace(params[k + "L"], params[k + "R"], n_test, dtype=torch.float64) for k in "xyz"]
+        w = [torch.tensor(simpson_weights(a.numpy()), device=device, dtype=torch.float64) for a in ax]
+        axd = [a.to(device) for a in ax]
+        xg, yg, zg = torch.meshgrid(*axd, indexing="ij")
+        pts = [t.reshape(-1).to(torch.float32) for t in (xg, yg, zg)]
+        if len(_GRID_CACHE) >= 4:
+            _GRID_CACHE.clear()
+        hit = _GRID_CACHE[key] = (ax, w, pts)
+    return hit
 
 
-def _integrate(ax, f):
-    """nested Simpson over z, y, x of f[n,n,n] (integra3d, poc/main.py:179-186)."""
-    w = [torch.tensor(simpson_weights(a.numpy()), device=f.device, dtype=torch.float64) for a in ax]
-    return float(torch.einsum("i,j,k,ijk->", w[0], w[1], w[2], f.double()))
+def _integrate(model, w, u, v=None):
+    """nested Simpson over z, y, x of u * v on the grid (integra3d, poc/main.py:179-186): one pinn_quadrature3d
+    launch pair on the device (fp64 accumulation, fixed order); u, v: fp32 per-point tensors (v None: u^2)."""
+    dev = u.device
+    h = model._handle_for(dev, u.numel())
+    scratch = torch.empty(w[0].numel(), device=dev, dtype=torch.float64)
+    out = torch.empty(1, device=dev, dtype=torch.float64)
+    h.quadrature3d(u.contiguous(), None if v is None else v.contiguous(), w[0], w[1], w[2], scratch, out)
+    return out
 
 
 def energy_from_psi(Ri, params, model):
-    """-> (E_integral, E_net) at nuclear half-distance Ri (poc/main.py:438-464)."""
+    """-> (E_integral, E_net) at nuclear half-distance Ri (poc/main.py:438-464).  Everything stays on the device:
+    grid, fused forward (psi, E, residual in one launch), H psi = res + E psi, the two quadratures; one host read
+    at the end."""
     n = int(params["n_test"])
     dev = next(model.parameters()).device
-    ax, (x, y, z) = _grid(params, n, dev)
+    _, w, (x, y, z) = _grid(params, n, dev)
     R = torch.full_like(x, float(Ri))
     o = model.evaluate(x, y, z, R, want=("psi", "E", "res"))
-    psi = o["psi"].reshape(n, n, n).double()
-    hpsi = (o["res"] + o["E"] * o["psi"]).reshape(n, n, n).double()   # H psi = res + E psi
-    E_int = _integrate(ax, psi * hpsi) / _integrate(ax, psi * psi)
-    return E_int, float(o["E"][-1])
+    psi = o["psi"].reshape(-1)
+    hpsi = (o["res"] + o["E"] * o["psi"]).reshape(-1)                 # H psi = res + E psi
+    num, den = _integrate(model, w, psi, hpsi), _integrate(model, w, psi)
+    return float(num / den), float(o["E"][-1])
+
+
+def _integrate64(w, f):
+    """the same nested rule on an fp64 grid function f[n, n, n] that no kernel of the library produced (the LCAO
+    closed form, the Hellmann-Feynman integrand with its fp64 geometry factor): a weighted sum on the device"""
+    return torch.dot(torch.mv(torch.matmul(f, w[2]), w[1]), w[0])     # innermost axis first, as integra3d nests them
 
 
 def energy_from_psi_LCAO(Ri, params, device=None):
@@ -57,16 +83,15 @@ def energy_from_psi_LCAO(Ri, params, device=None):
     n = int(params["n_test"])
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
-    ax, (x, y, z) = _grid(params, n, device)
-    x, y, z = x.double(), y.double(), z.double()
-    r1 = torch.sqrt((x - Ri) ** 2 + y ** 2 + z ** 2)
-    r2 = torch.sqrt((x + Ri) ** 2 + y ** 2 + z ** 2)
+    ax, w, _ = _grid(params, n, device)
+    xg, yg, zg = torch.meshgrid(*[a.to(device) for a in ax], indexing="ij")   # fp64: this curve is a closed form
+    r1 = torch.sqrt((xg - Ri) ** 2 + yg ** 2 + zg ** 2)
+    r2 = torch.sqrt((xg + Ri) ** 2 + yg ** 2 + zg ** 2)
     f1, f2 = torch.exp(-r1), torch.exp(-r2)
     psi = f1 + f2
     lap = f1 * (1 - 2 / r1) + f2 * (1 - 2 / r2)
     hpsi = -0.5 * lap - (1 / r1 + 1 / r2) * psi
-    shp = (n, n, n)
-    return _integrate(ax, (psi * hpsi).reshape(shp)) / _integrate(ax, (psi * psi).reshape(shp))
+    return float(_integrate64(w, psi * hpsi) / _integrate64(w, psi * psi))
 
 
 def dEdR_int(Ri, params, model):
@@ -75,16 +100,17 @@ def dEdR_int(Ri, params, model):
     forward kernel, dV/dR in closed form as in hamiltonian_R (poc/main.py:639-644)."""
     n = int(params["n_test"])
     dev = next(model.parameters()).device
-    ax, (x, y, z) = _grid(params, n, dev)
+    ax, w, (x, y, z) = _grid(params, n, dev)
     R = torch.full_like(x, float(Ri))
-    psi = model.evaluate(x, y, z, R, want=("psi",))["psi"].reshape(-1).double()
-    x, y, z = x.double(), y.double(), z.double()
-    r1 = torch.sqrt((x - Ri) ** 2 + y ** 2 + z ** 2)
-    r2 = torch.sqrt((x + Ri) ** 2 + y ** 2 + z ** 2)
-    VR = -(x - Ri) / r1.pow(3) + (x + Ri) / r2.pow(3)
+    psi = model.evaluate(x, y, z, R, want=("psi",))["psi"].reshape(-1)
+    xg, yg, zg = [t.reshape(-1) for t in torch.meshgrid(*[a.to(dev) for a in ax], indexing="ij")]   # fp64 geometry
+    r1 = torch.sqrt((xg - Ri) ** 2 + yg ** 2 + zg ** 2)
+    r2 = torch.sqrt((xg + Ri) ** 2 + yg ** 2 + zg ** 2)
+    VR = -(xg - Ri) / r1.pow(3) + (xg + Ri) / r2.pow(3)
     shp = (n, n, n)
-    norm = _integrate(ax, (psi * psi).reshape(shp))
-    return _integrate(ax, (psi * VR * psi).reshape(shp)) / norm - 1 / (2 * Ri ** 2)
+    psid = psi.double()
+    norm = _integrate64(w, (psid * psid).reshape(shp))
+    return float(_integrate64(w, (psid * VR * psid).reshape(shp)) / norm) - 1 / (2 * Ri ** 2)
 
 
 def force_curves(model, R):

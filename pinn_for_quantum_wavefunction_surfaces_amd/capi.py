@@ -15,7 +15,7 @@ PINN_PREC_F32, PINN_PREC_BF16, PINN_PREC_BF16X3 = 0, 1, 2
 EXPORTS = ["pinn_param_count", "pinn_tensor_count", "pinn_tensor_layout", "pinn_strerror",
            "pinn_create", "pinn_destroy", "pinn_last_error", "pinn_sample", "pinn_forward",
            "pinn_residual_fwd_bwd", "pinn_adam", "pinn_profile_enable", "pinn_profile_read",
-           "pinn_energy_R", "pinn_xchg_create", "pinn_xchg_local_handle", "pinn_xchg_connect",
+           "pinn_energy_R", "pinn_quadrature3d", "pinn_xchg_create", "pinn_xchg_local_handle", "pinn_xchg_connect",
            "pinn_xchg_allreduce", "pinn_xchg_set_timeout", "pinn_xchg_status", "pinn_xchg_destroy", "pinn_xchg_last_error"]
 
 
@@ -67,6 +67,7 @@ def load_library():
         [C.c_float] * 5 + [fp] * 4 + [vp, i64p, vp]
     lib.pinn_forward.argtypes = [vp] + [fp] * 5 + [C.c_int64, C.POINTER(Ham)] + [fp] * 4 + [vp]
     lib.pinn_energy_R.argtypes = [vp, fp, fp, C.c_int64, fp, fp, fp, vp]
+    lib.pinn_quadrature3d.argtypes = [vp, fp, fp, fp, fp, fp, C.c_int64, C.c_int64, C.c_int64, fp, fp, vp]
     lib.pinn_residual_fwd_bwd.argtypes = [vp] + [fp] * 5 + [vp, C.c_int64, C.POINTER(Ham), i64p,
                                                              C.c_uint64, fp, vp]
     lib.pinn_adam.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_double] * 4 + [C.c_uint64, fp, fp, vp]
@@ -162,6 +163,13 @@ class Handle:
     def energy_R(self, theta, R, n, E=None, dE=None, d2E=None):
         self._check(self.lib.pinn_energy_R(self.h, _ptr(theta), _ptr(R), n, _ptr(E), _ptr(dE),
                                            _ptr(d2E), self._stream()), "pinn_energy_R")
+
+    def quadrature3d(self, u, v, wx, wy, wz, scratch, out):
+        """out[0] = sum_ijk wx_i wy_j wz_k u_ijk v_ijk (v None: u squared); u, v fp32 device tensors of
+        nx*ny*nz values, weights and scratch (nx) and out (1) fp64 device tensors"""
+        self._check(self.lib.pinn_quadrature3d(self.h, _ptr(u), _ptr(v), _ptr(wx), _ptr(wy), _ptr(wz),
+                                               wx.numel(), wy.numel(), wz.numel(), _ptr(scratch), _ptr(out),
+                                               self._stream()), "pinn_quadrature3d")
 
     def residual_fwd_bwd(self, theta, x, y, z, R, mask, n, ham, bc_counts, trainable_mask, out):
         self._check(self.lib.pinn_residual_fwd_bwd(self.h, _ptr(theta), _ptr(x), _ptr(y), _ptr(z),

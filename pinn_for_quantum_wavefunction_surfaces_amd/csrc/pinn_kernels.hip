@@ -955,6 +955,42 @@ __global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t
     }
 }
 
+// ------------------------------------------------------------------ 3-D quadrature (integra3d)
+// plane i of the grid: block i sums wy[j] wz[k] u v over its ny x nz points in fp64 (thread-strided, then a
+// fixed-order LDS tree), the second kernel adds the nx plane sums times wx[i] in index order
+constexpr int kQuadBlock = 256;
+__global__ __launch_bounds__(kQuadBlock) void k_quad_planes(const float* __restrict__ u, const float* __restrict__ v,
+                                                            const double* __restrict__ wy, const double* __restrict__ wz,
+                                                            int64_t ny, int64_t nz, double* __restrict__ plane)
+{
+    __shared__ double sh[kQuadBlock];
+    const unsigned m = (unsigned)(ny * nz), nzu = (unsigned)nz;       // (the host checks ny * nz < 2^31)
+    const float* up = u + (size_t)blockIdx.x * m;
+    const float* vp = v ? v + (size_t)blockIdx.x * m : up;
+    double acc = 0.0;
+    for (unsigned t = threadIdx.x; t < m; t += kQuadBlock) {
+        const unsigned j = t / nzu, k = t - j * nzu;
+        acc += wy[j] * wz[k] * ((double)up[t] * (double)vp[t]);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kQuadBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) plane[blockIdx.x] = sh[0];
+}
+
+__global__ void k_quad_final(const double* __restrict__ plane, const double* __restrict__ wx, int64_t nx,
+                             double* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int64_t i = 0; i < nx; i++) s += wx[i] * plane[i];
+        *out = s;
+    }
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -1411,6 +1447,24 @@ extern "C" int pinn_energy_R(pinn_handle* h, const float* theta, const float* R,
         hipLaunchKernelGGL(k_energy_R<PINN_ACT_TANH>, grid, dim3(64), lds, st, theta + h->PT, a.HE, R, n, E, dE, d2E);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_energy_R", e);
+    return PINN_OK;
+}
+
+extern "C" int pinn_quadrature3d(pinn_handle* h, const float* u, const float* v, const double* wx,
+                                 const double* wy, const double* wz, int64_t nx, int64_t ny, int64_t nz,
+                                 double* scratch, double* out, void* stream)
+{
+    if (!h) return PINN_ERR_ARG;
+    if (!u || !wx || !wy || !wz || !scratch || !out) return fail(h, PINN_ERR_ARG, "null pointer");
+    if (nx < 1 || ny < 1 || nz < 1 || nx > 65535 * 32 || ny * nz >= ((int64_t)1 << 31))
+        return fail(h, PINN_ERR_ARG, "grid size");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_quad_planes, dim3((unsigned)nx), dim3(kQuadBlock), 0, st, u, v, wy, wz, ny, nz, scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_quad_planes", e);
+    hipLaunchKernelGGL(k_quad_final, dim3(1), dim3(64), 0, st, (const double*)scratch, wx, nx, out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_quad_final", e);
     return PINN_OK;
 }
 

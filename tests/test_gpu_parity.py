@@ -1621,3 +1621,52 @@ def test_one_shot_exchange_reports_a_missing_peer(tmp_path):
     s.close()
     mp.spawn(_xchg_timeout_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "timeout_reported").exists()
+
+
+# ----------------------------------------------------------------------------- the driver's contract
+BENCH_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _run_bench(args, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]                 # ONE line on stdout: the JSON record
+    return json.loads(lines[0])
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """bench.py as the driver runs it (bare, N = 1), shortened: one JSON line on stdout carrying the contract's
+    fields, a live roofline object measured in the run and the CPU baseline with the parity numbers observed"""
+    d = _run_bench(["--steps", "3", "--warmup", "1", "--points", "100000", "--no-secondary"])
+    assert BENCH_KEYS <= set(d), BENCH_KEYS - set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "points/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert abs(d["value"] - 100000 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["kernel_ms"] <= d["ms_per_step"]       # the dominant kernel fits inside the step
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    po = d["parity_observed"]
+    assert po["psi"] < 1e-2 and po["E"] < 1e-5 and po["grad"] < 3e-2
+
+
+def test_bench_starts_its_own_ranks_two_on_one_gpu():
+    """`python bench.py --gpus 2` without a launcher around it: it starts its two ranks itself (rehearsed on this
+    one-GPU box with both ranks on cuda:0 and gloo as the transport) and rank 0 prints the one line"""
+    d = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "50000"],
+                   {"PINN_REHEARSE_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 100000 and d["config"]["parallelism"] == "dp2"
+    assert "secondary" in d and d["secondary"] == [] and "cpu_baseline" not in d
+    d1 = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "50000", "--one-shot"],
+                    {"PINN_REHEARSE_ONE_GPU": "1"})
+    assert d1["config"]["exchange"].startswith("one-shot") and d1["config"]["exchange_status"] == "ok"
+    assert np.isfinite(d1["loss"]["Ltot"])

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""diag_deep -- where does the gradient error of the 4x128 split-bf16 path on the reference-generated deep128
+"""diag_deep (test infrastructure: uses the oracle, hence under tests/) -- where does the gradient error of the 4x128 split-bf16 path on the reference-generated deep128
 fixture come from?  Compares default kernel (k_trunkDx) and the pass-by-pass kernel (PINN_MFMA_VARIANT=3), with and
 without the fixture's hand-placed points next to the nuclei, against the fixture / the fp64 oracle."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

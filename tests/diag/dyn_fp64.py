@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""dyn_fp64 (test infrastructure) -- does fp32 arithmetic change where the reference's training recipe ends up?
+The same recipe (Adam lr 8e-3, resampling every epoch during the first 90 %) from the same initial weights on the same
+Philox points, once on the fp64 CPU oracle (--cpu) and once on the GPU path (--gpu): loss trajectories side by side.
+    python tests/diag/dyn_fp64.py --cpu --n 20000 --epochs 2000 --seed 1 --out /tmp/cpu.npz
+    python tests/diag/dyn_fp64.py --gpu --n 20000 --epochs 2000 --seed 1 --out gpurun_out/gpu.npz"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import pinn_for_quantum_wavefunction_surfaces_amd as pkg  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--n", type=int, default=20000)
+    ap.add_argument("--epochs", type=int, default=2000)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--lr", type=float, default=8e-3)
+    ap.add_argument("--f32-theta", action="store_true", help="CPU: round theta to fp32 after every Adam step")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    params = pkg.set_params()
+    torch.manual_seed(args.seed)
+    model = pkg.NN_ion(params)
+    theta0 = model.flat_params().double().numpy()
+    L = np.zeros(args.epochs)
+    t0 = time.time()
+    if args.cpu:
+        from oracle import oracle as O
+        A, Hm = O.arch(), O.ham_A()
+        th = theta0.copy()
+        m, v = np.zeros_like(th), np.zeros_like(th)
+        pts = None
+        for t in range(args.epochs):
+            if t < 0.9 * args.epochs or pts is None:
+                pts = O.sample(12345, t, 0, args.n, 18.0, 0.2, 4.0, 0.005, 17.5)
+            x, y, z, R, mask, cnt = pts
+            lg = O.loss_grad(A, Hm, th, x, y, z, R, mask)
+            L[t] = lg["Ltot"]
+            O.adam(A, th, lg["grad"], m, v, t + 1, args.lr)
+            if args.f32_theta:
+                th[:] = th.astype(np.float32).astype(np.float64)
+            if t % 200 == 0:
+                print("cpu epoch %d Ltot %.3e (%.0f s)" % (t, L[t], time.time() - t0), flush=True)
+    else:
+        model = model.to("cuda")
+        tr = pkg.Trainer(model, params, n_points=args.n, lr=args.lr, seed=12345, device="cuda")
+        hist = torch.zeros(args.epochs, device="cuda")
+        for t in range(args.epochs):
+            tr.step(resample=t < 0.9 * args.epochs)
+            hist[t] = tr.grad[tr.P:].sum()
+        L = hist.double().cpu().numpy()
+    n = args.epochs
+    print("%s n=%d seed=%d: Ltot at " % ("cpu fp64" if args.cpu else "gpu", args.n, args.seed)
+          + ", ".join("%d: %.2e" % (e, L[e]) for e in (0, 10, 100, n // 4, n // 2, 3 * n // 4, n - 1))
+          + "; median [0.8n,0.9n) %.2e, last 5 %% %.2e, min %.2e at %d" % (
+              np.median(L[int(0.8 * n):int(0.9 * n)]), np.median(L[int(0.95 * n):]), L.min(), L.argmin()))
+    if args.out:
+        np.savez(args.out, L=L)
+
+
+if __name__ == "__main__":
+    main()

@@ -2,9 +2,9 @@
 """callers_bench -- the callers next to the hot path on the GPU path, timed:
 energy_from_psi at n_test = 80 (the reference's setting) and 250 (the size poc/main.py:1461 says needs "more than 32GB"
 with the autograd Laplacian), calculate_E_R (39 R values), dEdR_int, force_curves, psi_cut, with the published
-checkpoint's weights (tests/golden/g1_weights.npz).  `--cpu-ref N` also times the oracle's torch restatement of the
-reference formulation (nested autograd Laplacian, fp64, CPU) on an N^3 grid for comparison.
-    python tools/callers_bench.py [--cpu-ref 40]"""
+checkpoint's weights (tests/golden/g1_weights.npz).  (The CPU restatement of the reference beside it:
+tests/diag/callers_cpu_ref.py -- anything that touches oracle/ lives under tests/.)
+    python tools/callers_bench.py"""
 import argparse
 import os
 import sys
@@ -32,9 +32,7 @@ def timed(fn, reps=3):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cpu-ref", type=int, default=0)
-    args = ap.parse_args()
+    argparse.ArgumentParser().parse_args()
     dev = "cuda:0"
     params = pkg.set_params()
     model = pkg.NN_ion(params).to(dev)
@@ -57,23 +55,6 @@ def main():
         dt * 1e3, float(F[90])))
     dt, _ = timed(lambda: analysis.psi_cut(model, 2.0))
     print("psi_cut (1000 points on the x axis): %.2f ms" % (dt * 1e3))
-    if args.cpu_ref:
-        from oracle import torch_baseline as TB
-        n = args.cpu_ref
-        th = torch.tensor(np.load(os.path.join(ROOT, "tests", "golden", "g1_weights.npz"))["fineTune"], dtype=torch.float64)
-        ax = torch.linspace(-18, 18, n, dtype=torch.float64)
-        xg, yg, zg = torch.meshgrid(ax, ax, ax, indexing="ij")
-        col = lambda t: t.reshape(-1, 1).clone().requires_grad_(True)
-        x, y, z = col(xg), col(yg), col(zg)
-        Rr = torch.full_like(x, 1.0)
-        arch = dict(H=16, L=2, HE=32, HG=10, act=0, n_pass=2, out_scale=1.0)
-        ham = dict(a=-0.5, b=-1.0, c=-1.0, P=1.0)
-        t0 = time.perf_counter()
-        empty = torch.zeros(0, dtype=torch.long)
-        TB.loss_terms(th, arch, ham, x, y, z, Rr, empty, empty)
-        dt = time.perf_counter() - t0
-        print("reference formulation (PyTorch CPU, fp64, nested autograd Laplacian, %d threads) psi + H psi on a %d^3 grid: "
-              "%.2f s = %.2e points/s" % (torch.get_num_threads(), n, dt, n ** 3 / dt))
 
 
 if __name__ == "__main__":

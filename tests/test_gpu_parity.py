@@ -1717,3 +1717,47 @@ def test_every_tile_boundary_size_matches_oracle(target):
         worst = max(worst, e)
         assert e < tol_g, (n, e)
     print("size sweep %s: worst loss/gradient error %.2e over %d sizes" % (target, worst, len(sizes)))
+
+
+# ----------------------------------------------------------------------------- a whole training run against the oracle
+def test_training_run_tracks_the_fp64_oracle_epoch_by_epoch():
+    """The reference's recipe in small (Adam lr 8e-3, fresh points every epoch during the first 90 %, the same batch
+    afterwards; 4 096 points, 400 epochs) on the GPU path and on the fp64 oracle, from the same nn.Linear-style start and
+    on the same Philox points: the loss of EVERY epoch, the weights after the last one and the E(R) curve they give agree
+    to fp32 round-off -- no drift, while the loss falls by four orders of magnitude.  (tests/diag/dyn_fp64.py is the
+    long form: 2 000 epochs at 20 000 points, max deviation of an epoch's loss 9.4e-6, median 1.2e-6.)"""
+    n, epochs, lr = 4096, 400, 8e-3
+    params = pkg.set_params()
+    torch.manual_seed(3)
+    model = pkg.NN_ion(params)
+    theta = model.flat_params().double().numpy().copy()
+    A, Hm = O.arch(), O.ham_A()
+    m, v = np.zeros_like(theta), np.zeros_like(theta)
+    Lref = np.zeros(epochs)
+    pts = None
+    for t in range(epochs):
+        if t < 0.9 * epochs:
+            pts = O.sample(12345, t, 0, n, 18.0, 0.2, 4.0, 0.005, 17.5)
+        x, y, z, R, mask, _ = pts
+        lg = O.loss_grad(A, Hm, theta, x, y, z, R, mask)
+        Lref[t] = lg["Ltot"]
+        O.adam(A, theta, lg["grad"], m, v, t + 1, lr)
+    tr = pkg.Trainer(model.to(DEV), params, n_points=n, lr=lr, seed=12345, device=DEV)
+    hist = torch.zeros(epochs, device=DEV)
+    for t in range(epochs):
+        tr.step(resample=t < 0.9 * epochs)
+        hist[t] = tr.grad[tr.P:].sum()
+    L = hist.double().cpu().numpy()
+    dev = np.abs(L / Lref - 1)
+    print("training run vs fp64 oracle: loss %.2e -> %.2e, deviation per epoch max %.2e median %.2e" % (
+        Lref[0], Lref[-1], dev.max(), np.median(dev)))
+    assert Lref[-1] < 1e-3 * Lref[0]
+    assert dev.max() < 2e-4 and np.median(dev) < 2e-5
+    th = tr.theta.double().cpu().numpy()
+    assert rel(th, theta) < 1e-4
+    Rg = np.round(np.arange(0.2, 4.05, 0.1), 2)
+    zero = np.zeros_like(Rg)
+    E_ref = O.forward(A, Hm, theta, zero + 0.3, zero, zero, Rg)["E"]
+    tr.sync_to_model()
+    E = model.energy_R(torch.tensor(Rg, device=DEV, dtype=torch.float32))[0].double().cpu().numpy()
+    assert np.abs(E - E_ref).max() < 2e-5

@@ -26,17 +26,20 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lr", type=float, default=8e-3)
     ap.add_argument("--f32-theta", action="store_true", help="CPU: round theta to fp32 after every Adam step")
+    ap.add_argument("--wide", choices=["", "bf16", "bf16x3"], default="",
+                    help="the benchmark's 2x64 tanh network instead of the reference architecture (GPU: this precision)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     params = pkg.set_params()
     torch.manual_seed(args.seed)
-    model = pkg.NN_ion(params)
+    model = (pkg.NN_ion(params, 64, 32, 10, n_hidden=2, act="tanh", precision=args.wide) if args.wide
+             else pkg.NN_ion(params))
     theta0 = model.flat_params().double().numpy()
     L = np.zeros(args.epochs)
     t0 = time.time()
     if args.cpu:
         from oracle import oracle as O
-        A, Hm = O.arch(), O.ham_A()
+        A, Hm = (O.arch(H=64, act=1) if args.wide else O.arch()), O.ham_A()
         th = theta0.copy()
         m, v = np.zeros_like(th), np.zeros_like(th)
         pts = None

@@ -1761,3 +1761,37 @@ def test_training_run_tracks_the_fp64_oracle_epoch_by_epoch():
     tr.sync_to_model()
     E = model.energy_R(torch.tensor(Rg, device=DEV, dtype=torch.float32))[0].double().cpu().numpy()
     assert np.abs(E - E_ref).max() < 2e-5
+
+
+def test_two_handles_on_two_streams_are_independent(golden_dir):
+    """include/pinn.h: "a handle is not thread-safe; distinct handles / streams are independent".  Two handles (the
+    reference architecture and the 2x64 tanh bf16 one), each driven on its own stream, 20 interleaved training steps with
+    no synchronisation in between: every step's [gradient | losses] equals that of the same sequence run alone, bit for bit
+    (the handles own their scratch; the kernels' one-time attribute set-up is per kernel, not per handle)."""
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))["ionHsym"]
+    params = pkg.set_params()
+
+    def make(wide):
+        torch.manual_seed(5)
+        m = (pkg.NN_ion(params, 64, 32, 10, act="tanh", precision="bf16") if wide else pkg.NN_ion(params)).to(DEV)
+        if not wide:
+            m.load_flat_params(torch.tensor(w))
+        return pkg.Trainer(m, params, n_points=40000, lr=8e-3, device=DEV)
+
+    def run(trs, streams, steps=20):
+        out = [[] for _ in trs]
+        for _ in range(steps):
+            for k, (tr, st) in enumerate(zip(trs, streams)):
+                with torch.cuda.stream(st):
+                    tr.step()
+                    out[k].append(tr.grad.clone())
+        torch.cuda.synchronize()
+        return out
+
+    s1, s2 = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+    torch.cuda.synchronize()
+    alone = [run([make(False)], [s1])[0], run([make(True)], [s2])[0]]
+    both = run([make(False), make(True)], [s1, s2])
+    for k in range(2):
+        for t, (a, b) in enumerate(zip(alone[k], both[k])):
+            assert torch.equal(a, b), (k, t)

@@ -93,11 +93,11 @@ class _FusedLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gtot, gpde, gbc):
+        scaled = ctx.grad_flat * gtot.to(ctx.grad_flat.dtype)       # one multiply, then views per parameter
         grads, k = [], 0
         for shape, dtype, req in ctx.meta:
             n = int(np.prod(shape))
-            g = ctx.grad_flat[k:k + n]
-            grads.append((g.to(dtype) * gtot.to(dtype)).reshape(shape) if req else None)
+            grads.append(scaled[k:k + n].to(dtype).reshape(shape) if req else None)
             k += n
         return (None,) * 6 + tuple(grads)
 
@@ -229,11 +229,10 @@ class NN_ion(nn.Module):
         h = self._handle_for(x.device, n)
         theta = self.flat_params(x.device)
         xs = [self._f32(t) for t in (x, y, z, R)]
-        n1 = int((mask & 1).sum())
-        n2 = int(((mask >> 1) & 1).sum())
-        ham = self.ham(1.0 / n, 1.0 / n1 if n1 else 0.0, 1.0 / n2 if n2 else 0.0)
+        # boundary-set sizes stay on the device (bc_counts of pinn_residual_fwd_bwd): no host read per call
+        counts = torch.stack([(mask & 1).sum(), ((mask >> 1) & 1).sum()]).to(torch.int64)
         out = torch.empty(h.P + 3, device=x.device, dtype=torch.float32)
-        h.residual_fwd_bwd(theta, *xs, mask, n, ham, None, self.trainable_mask(), out)
+        h.residual_fwd_bwd(theta, *xs, mask, n, self.ham(1.0 / n, 0.0, 0.0), counts, self.trainable_mask(), out)
         return out
 
     def energy_R(self, R):

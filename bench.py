@@ -260,6 +260,9 @@ def main():
     rehearsal = os.environ.get("PINN_REHEARSE_ONE_GPU") == "1"
     if rehearsal:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():      # (counting devices does not initialise the GPU)
+        sys.exit("bench.py: rank %d needs GPU %d but this node shows %d device(s); --gpus must not exceed the GPUs of "
+                 "ONE node" % (rank, local_rank, torch.cuda.device_count()))
     # stdout carries ONE line, the JSON record.  Library banners (RCCL prints its version to stdout when the
     # first communicator is built, gloo its connection notes) would precede it, so in distributed runs file
     # descriptor 1 points at stderr until the record is written to the saved descriptor.

@@ -2454,10 +2454,14 @@ struct TDCfg {
     static_assert(OFF_S % 16 == 0 && OFF_R % 16 == 0, "alignment");
 };
 
-template <int H, int L, int ACT>
+// VAR (measurement variants, tools/kbench.py): bit 0 = exchange slots lane-linear (round 3's layout) instead of swizzled;
+// bit 1 = waves WAVES/2.. (the younger SIMD partners, which lose the age-based issue arbitration) at s_setprio 1;
+// bit 2 = every wave at s_setprio 2 for the first pass of a phase and 0 for the second (the partner that is behind wins).
+template <int H, int L, int ACT, int VAR = 0>
 __global__ __launch_bounds__((TDCfg<H, L>::WAVES * 64), (TDCfg<H, L>::OCC * TDCfg<H, L>::WAVES / 4))
 void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, uint4* __restrict__ stash_g, TrunkArgs A)
 {
+    constexpr bool SWZ = (VAR & 1) == 0, PRIO_STATIC = (VAR & 2) != 0, PRIO_DYN = (VAR & 4) != 0;
     using C = TDCfg<H, L>;
     using Lay = TrunkLayout<H, L>;
     constexpr int HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB, NW = C::NW;
@@ -2478,8 +2482,19 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row tile owned by this wave
     const int g = lane >> 4, c = lane & 15;
     const int lane16 = lane * 16;
-    const int own_slot = lane16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
-    const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
+    // Slot of lane (g, c) inside a 1 KB (k chunk, stream) block of an exchange buffer: lane-linear, or (SWZ) with the
+    // 16-byte slots of the odd lane groups permuted by c ^ 12.  The transposed reads of the weight gradient fetch, per
+    // 32-lane service group, the slots c' in {0-3, 8-11} (then {4-7, 12-15}) of TWO adjacent lane groups, which the
+    // linear layout puts on the same banks (2-way conflict: half the LDS rate in the weight-gradient phases, where
+    // eight waves read 2 x 36 fragments per layer and tile); c ^ 12 moves the odd group's to the other banks and keeps
+    // the 16-byte fragment reads (hardware groups {0-3, 12-15, 20-27}, ...) and the 8-byte stores conflict-free.
+    auto slot16 = [](int gg, int cc) { return (gg * 16 + (SWZ ? (cc ^ ((gg & 1) * 12)) : cc)) * 16; };
+    const int sw16 = slot16(g, c);
+    const int own_slot = sw16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
+    // transposed read: this lane fetches half (c & 1) of the slot of source lane (g' = (c & 3) >> 1 [+ 2 (T & 1)],
+    // c' = 8 (g & 1) + (c >> 2) [+ 4 for the second read]) of stream pair member g >> 1
+    const int trl = (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2)) + (c & 1) * 8;
+    const int trh = SWZ ? (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2) + 4) + (c & 1) * 8 : trl + 64;
     const int n0 = 16 * part + 4 * g;                                    // first own neuron of this lane
 
     for (int k = threadIdx.x; k < H; k += NT) {
@@ -2559,12 +2574,12 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + own_slot + s * 1024) = pack4(v);
     };
     auto bfrag = [&](lds_p eb, int kc, int s) {
-        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + lane16 + (kc * NST + s) * 1024);
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + sw16 + (kc * NST + s) * 1024);
     };
     auto trfrag = [&](lds_p eb, int T, int ph) {     // rows 32ph..32ph+31 of the [column][neuron] image, tile T
-        const lds_p p0 = eb + trl + ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 64));
+        const int o = ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trl + o));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trh + o));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
     // D[own 16 rows][NST column tiles of ONE pass] += A x B: A fragments in registers, B fragments from the pass
@@ -2629,6 +2644,16 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     if (RPF) nxt = load_rec(0);
     bf16x8 afr[KC];
     loadA(0, afr);
+    // -DPINN_STAMPS (diagnostic build, tools/stamps.py): per-wave cycle totals of the phases and barrier waits
+#ifdef PINN_STAMPS
+    unsigned long long st_acc[24], st_last = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < 24; i++) st_acc[i] = 0;
+#define TD_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define TD_STAMP(i) do { } while (0)
+#endif
+    if (PRIO_STATIC && part >= C::WAVES / 2) __builtin_amdgcn_s_setprio(1);
     for (int64_t itx = 0; itx < iters; itx++) {
         const int64_t tile = itx * gridDim.x + blockIdx.x;
         const int64_t idx = tile * 16 + c;
@@ -2644,6 +2669,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             }
             __syncthreads();
         }
+        TD_STAMP(22);
         // ================= layer 0 of both passes -> X[0] =================
         {
             float inA[2][NST];
@@ -2665,7 +2691,9 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 put(X0 + ps * EB, SLP, s1 * a[SLP] + s2 * q);
             }
         }
+        TD_STAMP(0);
         __syncthreads();
+        TD_STAMP(1);
         // ================= layers 1 .. L-1 =================
         u32x2 sv[STASH ? 1 : (NW > 1 ? NW - 1 : 1)][2][NST];   // packed saved state of layers 1..L-2 (registers)
         f32x4 svl[2][NST];                                      // (h, a_x, a_rho, a_lap) of the last hidden layer
@@ -2674,9 +2702,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             const lds_p Xin = lds0 + C::OFF_X + (size_t)(l - 1) * 2 * EB;
             const lds_p Xout = lds0 + C::OFF_X + (size_t)l * 2 * EB;      // (not used by the last layer)
             float Sv = 0.f, Sl = 0.f;
-#pragma unroll
-            for (int ps = 0; ps < 2; ps++) {
-                f32x4 acc[NST];
+            auto fwdG = [&](int ps, f32x4 (&acc)[NST]) {
                 acc[0] = *reinterpret_cast<const f32x4*>(sbl + (l - 1) * H + n0);
 #pragma unroll
                 for (int s = 1; s < NST; s++) acc[s] = splat(0.f);
@@ -2686,6 +2712,8 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                     loadA(l < L - 1 ? l * 2 : (L - 2) * 2 + 1, afr);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            };
+            auto fwdE = [&](int ps, f32x4 (&acc)[NST]) {
                 f32x4 s0, s1, s2;
                 act012v<ACT>(acc[0], s0, s1, s2);
                 const f32x4 q = acc[1] * acc[1] + acc[2] * acc[2];
@@ -2715,12 +2743,21 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                     Sv += pw * dot4(wo, s0);
                     Sl += pw * dot4(wo, ol);
                 }
+            };
+#pragma unroll
+            for (int ps = 0; ps < 2; ps++) {
+                if (PRIO_DYN) { if (ps == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+                f32x4 acc[NST];
+                fwdG(ps, acc);
+                fwdE(ps, acc);
             }
             if (l == L - 1) {
                 const float tot = xg_sum_pair(Sv, Sl);          // Sv in lane groups 0,1; Sl in groups 2,3
                 if ((g & 1) == 0) SB[(part * 16 + c) * 2 + (g >> 1)] = tot;
             }
+            TD_STAMP(2 * l);
             __syncthreads();
+            TD_STAMP(2 * l + 1);
         }
         // ================= tail, adjoints of the last hidden layer -> YB =================
         {
@@ -2763,7 +2800,9 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 put(YB + ps * EB, SLP, s1 * ol);
             }
         }
+        TD_STAMP(8);
         __syncthreads();
+        TD_STAMP(9);
         // ================= reverse steps l = L-1 .. 1 =================
 #pragma unroll
         for (int l = L - 1; l >= 1; l--) {
@@ -2775,6 +2814,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                     for (int ps = 0; ps < 2; ps++) { sq[ps][0] = stash_get(l - 1, 2 * ps); sq[ps][1] = stash_get(l - 1, 2 * ps + 1); }
                 }
             }
+            if (PRIO_DYN) __builtin_amdgcn_s_setprio(2);
             wgrad(wacc[l - 1], YB, Xin);
             u32x2 yp[2][NST];               // adjoints of layer l-1, packed: written to YB once every wave has read it
             float inA[2][NST];
@@ -2790,6 +2830,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 f32x4 ob[NST];
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
+                if (PRIO_DYN && ps == 1) __builtin_amdgcn_s_setprio(0);
                 gemmP(afr, YB + ps * EB, ob);
                 if (ps == 1) {
                     // next A fragments: the transposed matrix of layer l-1, or layer 1 forward for the next tile
@@ -2835,17 +2876,28 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                     for (int s = 0; s < NST; s++) { fmac_bcast(w0acc0, ab[s], inA[ps][s]); fmac_bcast(w0acc1, ab[s], inA[1 - ps][s]); }
                 }
             }
+            TD_STAMP(10 + 4 * (L - 1 - l));
             __syncthreads();                    // every wave has read YB (and X[l-1])
+            TD_STAMP(11 + 4 * (L - 1 - l));
             if (l > 1) {
 #pragma unroll
                 for (int ps = 0; ps < 2; ps++)
 #pragma unroll
                     for (int s = 0; s < NST; s++)
                         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(YB + ps * EB + own_slot + s * 1024) = yp[ps][s];
+                TD_STAMP(12 + 4 * (L - 1 - l));
                 __syncthreads();
+                TD_STAMP(13 + 4 * (L - 1 - l));
             }
         }
     }
+#ifdef PINN_STAMPS
+    if (A.psi && lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.psi) + ((size_t)blockIdx.x * C::WAVES + part) * 24;
+        for (int i = 0; i < 24; i++) dbg[i] = st_acc[i];
+    }
+#endif
+#undef TD_STAMP
     // =========================== block reduction ===========================
     __syncthreads();
     constexpr int PT = Lay::size;
@@ -2891,7 +2943,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     if (threadIdx.x == 3) out[Lay::bout] = sc[3];
 }
 
-template <int H, int L, int ACT>
+template <int H, int L, int ACT, int VAR = 0>
 hipError_t launch_trunkD_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
 {
     using C1 = MCfg<H, L>;
@@ -2900,7 +2952,7 @@ hipError_t launch_trunkD_t(const float* theta, __bf16* wpk, const TrunkArgs& A, 
     hipLaunchKernelGGL((k_pack_weights<H, L, false>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    auto kern = k_trunkD<H, L, ACT>;
+    auto kern = k_trunkD<H, L, ACT, VAR>;
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -4194,6 +4246,14 @@ bool launch_trunk_mfma_128x4(int act, int npass, int mode, bool x3, int variant,
               // layer-output buffer (XONE)
         return launch2_HL<128, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (npass == 2 && mode == MODE_BWD && variant != 3) {
+        if (act == ACT_TANH && variant >= 11 && variant < 18) {   // measurement variants (tools/kbench.py): VAR = variant - 10
+            switch (variant - 10) {
+            case 1: *err = launch_trunkD_t<128, 4, ACT_TANH, 1>(theta, wpk, A, grid, st); return true;
+            case 2: *err = launch_trunkD_t<128, 4, ACT_TANH, 2>(theta, wpk, A, grid, st); return true;
+            case 4: *err = launch_trunkD_t<128, 4, ACT_TANH, 4>(theta, wpk, A, grid, st); return true;
+            default: break;
+            }
+        }
         *err = act == ACT_TANH ? launch_trunkD_t<128, 4, ACT_TANH>(theta, wpk, A, grid, st)
                                : launch_trunkD_t<128, 4, ACT_SIGMOID>(theta, wpk, A, grid, st);
         return true;

@@ -14,6 +14,7 @@ What is produced:
   g1_weights.npz   both checkpoints as flat fp64 vectors (state_dict order)
   g2_formA_*.npz   NN_ion (poc/main.py) on a fixed batch: psi,E,lap,Hpsi,res,losses,grads
                    (tanh64 / tanh16: the same module with its `sig` handle set to nn.Tanh())
+                   (tanh64, deep128 also carry fp32_*: the same module run in fp32 torch on the same batch)
                    (deep128 / deep16: NN_ion with Lin_H3(, Lin_H4) added the way the reference's own
                    commented-out line poc/main.py:302 does -- only `base` is overridden; forward,
                    LossFunctions, lapl and the third-order autograd are the reference's)
@@ -146,6 +147,30 @@ def as_col(a, grad=False):
 
 
 # ------------------------------------------------------------ formulation A
+def eval_form_A_fp32(ns, model, x, y, z, R, grad_order=None):
+    """The SAME module and statements run in fp32 torch (weights and points rounded to fp32): what genuine fp32
+    arithmetic of the reference formulation gives on this batch -- the yardstick for an "fp32" path (round 4:
+    the GPU tests hold the split-bf16 kernels to a multiple of THIS error instead of to a measured sensitivity)."""
+    import copy
+    params = ns["params"]
+    m32 = copy.deepcopy(model).float()
+    col = lambda a: torch.tensor(np.asarray(a, dtype=np.float64).reshape(-1, 1)).float().requires_grad_(True)
+    xt, yt, zt, Rt = col(x), col(y), col(z), col(R)
+    r1, r2 = ns["radial"](xt, yt, zt, Rt, params)
+    b1 = torch.where(r1 >= params["BCcutoff"])
+    b2 = torch.where(r2 >= params["BCcutoff"])
+    psi, E = m32.parametricPsi(xt, yt, zt, Rt)
+    lap = ns["lapl"](xt, yt, zt, psi)
+    m32.zero_grad()
+    Ltot, _, _, _ = m32.LossFunctions(xt, yt, zt, Rt, params, b1, b2)
+    Ltot.backward()
+    named = dict(m32.named_parameters())
+    keys = grad_order or [k + s_ for k in STATE_KEYS for s_ in (".weight", ".bias")]
+    grad = np.concatenate([named[k].grad.detach().double().numpy().ravel() for k in keys])
+    d = lambda t: t.detach().double().numpy().ravel().copy()
+    return dict(fp32_psi=d(psi), fp32_lap=d(lap), fp32_Ltot=float(Ltot.detach()), fp32_grad=grad)
+
+
 def eval_form_A(ns, model, x, y, z, R):
     params = ns["params"]
     xt, yt, zt, Rt = as_col(x, True), as_col(y, True), as_col(z, True), as_col(R, True)
@@ -193,6 +218,7 @@ def gen_form_A(ns):
     m64 = NN_ion(params, 64, 32, 10)
     m64.sig = torch.nn.Tanh()
     out["tanh64"] = eval_form_A(ns, m64, xs, ys, zs, Rs)
+    out["tanh64"].update(eval_form_A_fp32(ns, m64, xs, ys, zs, Rs))
     torch.manual_seed(19)
     m16 = NN_ion(params)
     m16.sig = torch.nn.Tanh()
@@ -230,6 +256,10 @@ def gen_form_A(ns):
         d["theta"] = deep_order(m, lambda k: sd[k].detach().numpy().ravel())
         d["grad"] = deep_order(m, lambda k: named[k].grad.detach().numpy().ravel())
         d["L"] = L
+        if tag == "deep128":   # BASELINE config 1's shape: the fp32-torch run of the same module on the same batch
+            keys = ["Lin_H%d" % k for k in range(1, L + 1)] + STATE_KEYS[2:]
+            d.update(eval_form_A_fp32(ns, m, xs[:n], ys[:n], zs[:n], Rs[:n],
+                                      [k + s_ for k in keys for s_ in (".weight", ".bias")]))
         out[tag] = d
     for tag, dct in out.items():
         if len(sys.argv) > 2 and tag not in sys.argv[2:]:
@@ -237,6 +267,12 @@ def gen_form_A(ns):
         np.savez_compressed(os.path.join(OUT, "g2_formA_%s.npz" % tag), **dct)
         print("g2_formA_%s: Ltot=%.6e |grad|=%.3e" % (tag, dct["Ltot"],
                                                       np.linalg.norm(dct["grad"])))
+        if "fp32_grad" in dct:
+            print("    fp32 torch on the same batch: grad %.3e of max|grad|, psi %.2e, lap %.2e, Ltot %.2e" % (
+                np.abs(dct["fp32_grad"] - dct["grad"]).max() / np.abs(dct["grad"]).max(),
+                np.abs(dct["fp32_psi"] - dct["psi"]).max() / np.abs(dct["psi"]).max(),
+                np.abs(dct["fp32_lap"] - dct["lap"]).max() / np.abs(dct["lap"]).max(),
+                abs(dct["fp32_Ltot"] / dct["Ltot"] - 1)))
 
 
 # ------------------------------------------------------------ formulation B

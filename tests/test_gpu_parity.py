@@ -140,31 +140,21 @@ def test_three_layer_trunk_matches_reference(golden_dir):
         assert np.max(np.abs(out[o:o + s_] - ref)) < 2e-4 * max(np.max(np.abs(ref)), 1e-3 * np.max(np.abs(g["grad"])))
 
 
-def _round_bf16_pieces(a, pieces):
-    """a rounded to the sum of `pieces` bf16 numbers (1: bf16 operands, 2: the split-bf16 kernels' hi + lo)"""
-    t = torch.tensor(a, dtype=torch.float32)
-    acc, r = torch.zeros_like(t), t.clone()
-    for _ in range(pieces):
-        p_ = r.to(torch.bfloat16).to(torch.float32)
-        acc += p_
-        r = r - p_
-    return acc.double().numpy()
-
-
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
 def test_4x128_trunk_matches_reference(golden_dir, prec):
     """BASELINE config 1's shape (4x128, tanh) pinned to the reference: NN_ion with hidden layers 3 and 4
     enabled the way its own commented-out line poc/main.py:302 does, its unchanged forward / lapl /
-    LossFunctions / autograd (make_golden.py, g2 deep128).  split-bf16 (k_trunkDx, the "fp32" of config 1)
-    at the fp32-grade bar, plain bf16 (k_trunkD) at the bf16 bar.
+    LossFunctions / autograd (make_golden.py, g2 deep128).  split-bf16 (k_trunkDx: 16 operand mantissa bits)
+    and plain bf16 (k_trunkD) at their paths' bars.
     Forward quantities and the loss: on the whole fixture, hand-placed points next to the nuclei included.
-    Gradient: (a) on the fixture without those 12 points at the path's usual bar, every tensor separately
-    (against the oracle, which this same fixture pins to the reference at 1e-12 for L = 4); (b) on the whole
-    fixture, where the 12 points (|res| up to 8.4 against a median of 0.016) contribute large terms that
-    cancel most of the rest -- the gradient of THIS batch is ill-conditioned: merely rounding the three dense
-    weight matrices to the kernels' operand precision moves it by 3.2e-4 (16 mantissa bits) / 0.16 (bf16)
-    in the fp64 oracle -- the error is held to 8 x that measured sensitivity (observed 4.5 x / 1.5 x, the same
-    on the two independent kernels of each precision)."""
+    Gradient, every tensor separately: on the fixture without those 12 points at the path's usual bar (against the
+    oracle, which this same fixture pins to the reference at 1e-12 for L = 4).
+    Gradient on the WHOLE fixture: the 12 points (|res| up to 8.4 against a median of 0.016) dominate the loss and
+    their gradient contributions cancel most of the others', so this batch's gradient is ill-conditioned in the
+    FORWARD residual at those points (tests/diag/diag_operand_bits.py: ~70 x; the reverse sweep's operand
+    precision does not matter).  The yardstick is what genuine fp32 arithmetic gives: the fixture carries the
+    gradient of the reference run in fp32 torch on the same batch (make_golden.py, `fp32_grad`: 1.47e-4 of the
+    largest entry).  The split-bf16 path is held to a stated multiple of THAT error."""
     g = np.load(os.path.join(golden_dir, "g2_formA_deep128.npz"))
     f = pkg.model.FORMULATION_A
     x3 = prec == "bf16x3"
@@ -177,27 +167,31 @@ def test_4x128_trunk_matches_reference(golden_dir, prec):
     out = run_loss_grad(h, f, g["theta"], *pts(slice(None)), g["mask"])
     errs = dict(psi=rel(psi, g["psi"]), E=rel(E, g["E"]), lap=rel(lap, g["lap"]), res=rel(res, g["res"]),
                 loss=abs(out[P:].sum() / g["Ltot"] - 1), grad=rel(out[:P], g["grad"]))
-    # (b) conditioning of this batch's gradient, measured with the oracle
-    off, sz = O.tensor_layout(A)
-    th_r = g["theta"].copy()
-    for t in (2, 4, 6):
-        th_r[off[t]:off[t] + sz[t]] = _round_bf16_pieces(g["theta"][off[t]:off[t] + sz[t]], 2 if x3 else 1)
-    sens = rel(O.loss_grad(A, Hm, th_r, *pts(slice(None)), g["mask"])["grad"], g["grad"])
-    # (a) without the hand-placed points
+    e32 = rel(g["fp32_grad"], g["grad"])          # the reference in fp32 torch, same batch, all 768 points
+    assert 1e-4 < e32 < 2e-4
+    # without the hand-placed points
     sl = slice(12, None)
     ref = O.loss_grad(A, Hm, g["theta"], *pts(sl), g["mask"][sl])
     out2 = run_loss_grad(h, f, g["theta"], *pts(sl), g["mask"][sl])
     errs["grad_regular"] = rel(out2[:P], ref["grad"])
     terr = _tensor_errors(arch, 4, out2[:P], ref["grad"])
-    print("4x128 %s vs reference:" % prec, {k: "%.2e" % v for k, v in {**errs, **terr}.items()}, "sensitivity %.2e" % sens)
+    print("4x128 %s vs reference:" % prec, {k: "%.2e" % v for k, v in {**errs, **terr}.items()},
+          "fp32 torch on the whole fixture %.2e -> ratio %.1f" % (e32, errs["grad"] / e32))
     assert errs["E"] < 1e-5
     if x3:
         assert errs["psi"] < 1e-5 and errs["lap"] < 1e-5 and errs["res"] < 5e-5 and errs["loss"] < 2e-4
         assert errs["grad_regular"] < 2e-4 and max(terr.values()) < 4e-4, terr
+        # whole fixture: 16-bit operands in the forward GEMMs (fp32: 24) -> observed 9.5 x the fp32 run's error
+        assert errs["grad"] < X3_WHOLE_FIXTURE_FACTOR * e32, (errs["grad"], e32)
     else:
         assert errs["psi"] < 1e-2 and errs["lap"] < 1e-2 and errs["res"] < 2e-2 and errs["loss"] < 3e-2
         assert errs["grad_regular"] < 3e-2 and max(terr.values()) < 6e-2, terr
-    assert errs["grad"] < 8 * sens, (errs["grad"], sens)
+        # whole fixture in plain bf16 (8 operand bits): observed 0.23 of the largest entry = 1 600 x the fp32 run's
+        # error; no bar would carry information here, the regular-points check above is the one that pins k_trunkD
+
+
+# whole-fixture gradient bar of the split-bf16 4x128 path in units of the fp32-torch error on the same batch
+X3_WHOLE_FIXTURE_FACTOR = 16.0
 
 
 def test_three_layer_tanh_small_Rnet_matches_oracle():
@@ -568,9 +562,11 @@ def test_benchmarked_2x64_tanh_instance_matches_reference(golden_dir, prec):
     if prec == "bf16":
         # bf16: the gate's gradient dL/dg = sum over points of (N psi-bar + lap N lap-bar) is a cancelling
         # sum of terms that carry the trunk's bf16 noise (observed 9-11 % of its own scale, which is a few
-        # per cent of the largest gradient entry); it is held by the whole-vector bar above (3e-2 of the
-        # largest entry), the per-tensor bar below covers the trunk and E-net tensors
+        # per cent of the largest gradient entry): its four tensors get a bar of their own, 20 % of their own
+        # scale; the trunk and E-net tensors stay at 6 %
+        gate = {k: v for k, v in terr.items() if k.startswith(("WG", "bG"))}
         terr = {k: v for k, v in terr.items() if not k.startswith(("WG", "bG"))}
+        assert max(gate.values()) < 0.2, gate
     assert errs["E"] < 1e-5
     if prec == "bf16":       # this path's own tolerance (header of this section)
         assert errs["psi"] < 1e-2 and errs["lap"] < 1e-2 and errs["res"] < 2e-2
@@ -602,7 +598,9 @@ def test_train_py_formulation_2x64_tanh_matches_reference(golden_dir, prec):
     print("train.py formulation 2x64 tanh %s vs reference:" % prec, {k: "%.2e" % v for k, v in {**errs, **terr}.items()})
     assert errs["E"] < 1e-5
     if prec == "bf16":
-        terr = {k: v for k, v in terr.items() if not k.startswith(("WG", "bG"))}   # (see the symmetric test above)
+        gate = {k: v for k, v in terr.items() if k.startswith(("WG", "bG"))}      # (see the symmetric test above)
+        terr = {k: v for k, v in terr.items() if not k.startswith(("WG", "bG"))}
+        assert max(gate.values()) < 0.2, gate
         assert errs["psi"] < 1e-2 and errs["res"] < 2e-2 and errs["loss"] < 3e-2 and errs["grad"] < 3e-2
         assert max(terr.values()) < 6e-2, terr
     else:

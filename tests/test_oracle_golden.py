@@ -222,4 +222,11 @@ def test_committed_fixtures_regenerate_bit_identically(tmp_path, golden_dir):
         a, b = np.load(f), np.load(os.path.join(str(tmp_path), os.path.basename(f)))
         assert sorted(a.files) == sorted(b.files), f
         for k in a.files:
+            if k.startswith("fp32_"):
+                # the reference run in fp32 torch (round 4): a measurement of fp32 round-off, whose last bits may depend
+                # on the BLAS build's summation order; held to 2 % of the fp32 error it records
+                ref64 = a[k[5:]]
+                err = np.max(np.abs(a[k] - ref64))
+                assert np.max(np.abs(a[k] - b[k])) <= 0.02 * err, (os.path.basename(f), k)
+                continue
             assert np.array_equal(a[k], b[k]), (os.path.basename(f), k)

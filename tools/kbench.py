@@ -52,9 +52,10 @@ def main():
             torch.cuda.synchronize()
             res[v].append(tr.h.profile_read(args.steps))
     for v in variants:
-        print("arch %s variant %d: trunk kernel ms median %.4f min %.4f  (rounds: %s)  loss %.4e" % (
+        # theta checksum: variants that only re-order or re-place work must agree bit for bit (same seed, same step count)
+        print("arch %s variant %d: trunk kernel ms median %.4f min %.4f  (rounds: %s)  loss %.4e  theta bits %d" % (
             args.arch, v, float(np.median(res[v])), min(res[v]), " ".join("%.4f" % t for t in res[v]),
-            trainers[v].losses()[0]))
+            trainers[v].losses()[0], int(trainers[v].theta.view(torch.int32).to(torch.int64).sum())))
 
 
 if __name__ == "__main__":

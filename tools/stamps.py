@@ -55,7 +55,9 @@ def main():
     m = pkg.NN_ion(params, a["H"], a["HE"], a["HG"], n_hidden=a["L"], act=a["act_name"], precision=a["precision"]).to(dev)
     tr = pkg.Trainer(m, params, n_points=args.points, lr=8e-3, seed=12345, device=dev)
     waves = a["H"] // 16
-    dbg = torch.zeros(4096 * waves * 8, device=dev, dtype=torch.int64)
+    deep = a["L"] == 4                     # k_trunkD: 24 slots per wave, k_trunk2: 8
+    NS = 24 if deep else 8
+    dbg = torch.zeros(4096 * waves * NS, device=dev, dtype=torch.int64)
     for _ in range(50):
         tr.step()
     torch.cuda.synchronize()
@@ -65,8 +67,10 @@ def main():
         tr.step()
     torch.cuda.synchronize()
     ms = tr.h.profile_read(4)
-    d = dbg.cpu().numpy().reshape(-1, 8)
+    d = dbg.cpu().numpy().reshape(-1, NS)
     d = d[d.sum(1) > 0].astype(np.float64)
+    if deep:
+        return report_deep(args, a, d, ms, waves)
     trips = (args.points + 15) // 16 / (d.shape[0] / waves)
     names = ["P1 inputs+layer0", "barrier 1", "P2 gemm+act", "barrier 2", "P3 tail+last hidden", "barrier 3",
              "P4 wgrad+adjoint+layer0", "loop top"]
@@ -76,6 +80,27 @@ def main():
     for i in (7, 0, 1, 2, 3, 4, 5, 6):
         print("  %-26s %7.0f cycles per trip  %5.1f %%   (min wave %.0f, max wave %.0f)" % (
             names[i], d[:, i].mean() / trips, 100 * d[:, i].mean() / tot, d[:, i].min() / trips, d[:, i].max() / trips))
+
+
+def report_deep(args, a, d, ms, waves):
+    import numpy as np
+    trips = (args.points + 15) // 16 / (d.shape[0] / waves)
+    names = {22: "loop top / ring refill", 0: "layer 0", 1: "  barrier", 2: "forward layer 1 (G E G E)", 3: "  barrier",
+             4: "forward layer 2", 5: "  barrier", 6: "forward layer 3 + output sums", 7: "  barrier", 8: "tail + last-hidden adjoints",
+             9: "  barrier", 10: "reverse 3: wgrad + 2 x (G, E)", 11: "  barrier", 12: "  adjoint stores", 13: "  barrier",
+             14: "reverse 2", 15: "  barrier", 16: "  adjoint stores", 17: "  barrier", 18: "reverse 1 (+ layer 0 adjoint)", 19: "  barrier"}
+    order = [22, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+    tot = d.sum(1).mean()
+    print("%s variant %s: stamped kernel %.4f ms, %d waves, %.1f trips per wave, %.0f cycles per trip (%.2f GHz implied)" % (
+        args.arch, os.environ.get("PINN_MFMA_VARIANT", "0"), ms, d.shape[0], trips, tot / trips, tot / (ms * 1e6)))
+    w = np.arange(d.shape[0]) % waves
+    lo, hi = d[w < waves // 2], d[w >= waves // 2]
+    bar = sum(d[:, i].mean() for i in order if names[i].startswith("  barrier"))
+    print("  %-32s %8s %6s   %8s %8s" % ("phase", "cycles", "%", "waves 0-3", "waves 4-7"))
+    for i in order:
+        print("  %-32s %8.0f %5.1f %%   %8.0f %8.0f" % (names[i], d[:, i].mean() / trips, 100 * d[:, i].mean() / tot,
+                                                      lo[:, i].mean() / trips, hi[:, i].mean() / trips))
+    print("  barrier waits in all: %.0f cycles per trip (%.1f %%)" % (bar / trips, 100 * bar / tot))
 
 
 if __name__ == "__main__":

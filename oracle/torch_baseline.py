@@ -79,3 +79,38 @@ def make_step(theta0, arch, ham, lr=8e-3, dtype=torch.float64):
         return float(Ltot.detach())
 
     return theta, step
+
+
+def make_step_chunked(theta0, arch, ham, lr=8e-3, dtype=torch.float64, chunk=100000):
+    """the same step on a batch too large for the host's memory in one autograd graph (~40 GB at
+    1 000 000 points in fp64): the boundary sets are found on the whole batch first, then the loss is accumulated
+    chunk by chunk -- sum(res^2)/N + sum(psi^2[i1])/N1 + sum(psi^2[i2])/N2, one backward per chunk into the same
+    .grad -- and Adam steps once.  Identical to the one-graph step in exact arithmetic."""
+    theta = theta0.clone().to(dtype).requires_grad_(True)
+    opt = torch.optim.Adam([theta], lr=lr)
+
+    def step(x, y, z, R):
+        x, y, z, R = [t.reshape(-1, 1).to(dtype) for t in (x, y, z, R)]
+        n = x.shape[0]
+        with torch.no_grad():
+            m1 = ((x - R) ** 2 + y ** 2 + z ** 2)[:, 0] >= 17.5 ** 2
+            m2 = ((x + R) ** 2 + y ** 2 + z ** 2)[:, 0] >= 17.5 ** 2
+            n1, n2 = int(m1.sum()), int(m2.sum())
+        opt.zero_grad()
+        total = 0.0
+        for lo in range(0, n, chunk):
+            sl = slice(lo, min(lo + chunk, n))
+            xc, yc, zc = [t[sl].clone().requires_grad_(True) for t in (x, y, z)]
+            i1, i2 = torch.where(m1[sl])[0], torch.where(m2[sl])[0]
+            _, _, _, psi, _, _, res = loss_terms(theta, arch, ham, xc, yc, zc, R[sl], i1, i2)
+            part = (res ** 2).sum() / n
+            if n1:
+                part = part + (psi[i1, 0] ** 2).sum() / n1
+            if n2:
+                part = part + (psi[i2, 0] ** 2).sum() / n2
+            part.backward()
+            total += float(part.detach())
+        opt.step()
+        return total
+
+    return theta, step

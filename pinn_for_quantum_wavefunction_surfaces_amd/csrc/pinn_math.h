@@ -70,6 +70,24 @@ template <> struct V2<float> { typedef float type __attribute__((vector_size(8))
 template <> struct V2<double> { typedef double type __attribute__((vector_size(16))); };
 template <class T> PINN_HD typename V2<T>::type splat2(T x) { typename V2<T>::type v = {x, x}; return v; }
 template <class T> PINN_HD typename V2<T>::type make2(T x, T y) { typename V2<T>::type v = {x, y}; return v; }
+// Broadcast of ONE element of a pair to both halves.  Written as splat2(v[i & 1]), hipcc reads the odd element in place
+// with v_pk_fma_f32 ... op_sel:[1,..] (the LOW result lane reading the HIGH dword of the operand pair) -- the form that
+// intermittently computed with 0 in place of that dword on MI355X when a matrix-pipe instruction was in flight
+// (profiles/r02_packed_opsel.md, r03_packed_opsel.md; cause open).  The odd element therefore takes a detour through a
+// register of its own (one v_mov_b32 per broadcast, against H/2 packed FMAs that use it), from which the broadcast is
+// the low-half form op_sel_hi:[0,..]; tests/test_host_cpu.py compiles this unit too and checks that none is left.
+PINN_HD float own_register(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mov_b32 %0, %1" : "=v"(x) : "v"(x));
+#endif
+    return x;
+}
+PINN_HD double own_register(double x) { return x; }
+template <class T> PINN_HD typename V2<T>::type bcast_elem(typename V2<T>::type v, int i)
+{
+    return splat2<T>((i & 1) ? own_register(v[1]) : v[0]);
+}
 
 // thT = theta with every matrix that the FORWARD pass contracts over its input index stored
 // input-major: W_l (l >= 1) and WE2 transposed in place, W_0 as [2][H].  Everything else is
@@ -290,7 +308,7 @@ struct TrunkPass {
                 PINN_ROW_FENCE();
 #pragma unroll
                 for (int s = 0; s < 5; s++) {
-                    const V xs = splat2<T>(o[l - 1][s][i >> 1][i & 1]);
+                    const V xs = bcast_elem<T>(o[l - 1][s][i >> 1], i);
 #pragma unroll
                     for (int p = 0; p < HP; p++) {
                         A[s][p] += wc[p] * xs;
@@ -426,7 +444,7 @@ struct TrunkPass {
                 PINN_ROW_FENCE();
 #pragma unroll
                 for (int s = 0; s < 5; s++) {
-                    const V xs = splat2<T>(ab[s][j >> 1][j & 1]);
+                    const V xs = bcast_elem<T>(ab[s][j >> 1], j);
 #pragma unroll
                     for (int p = 0; p < HP; p++) {
                         ob[s][p] += wc[p] * xs;

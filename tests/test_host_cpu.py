@@ -177,11 +177,13 @@ def test_torch_baseline_matches_oracle(golden_dir):
     assert np.abs(th.grad.numpy() - g["grad"]).max() / np.abs(g["grad"]).max() < 1e-11
 
 
-def test_no_packed_opsel_forms_in_the_matrix_pipe_kernels():
+def test_no_packed_opsel_forms_in_any_trunk_kernel():
     """hipcc's v_pk_{mul,fma,add}_f32 ... op_sel:[..] (the LOW result lane reading the HIGH dword of an operand
     pair) intermittently computed with 0 in place of that dword on MI355X (profiles/r02_packed_opsel.md,
-    tools/opselbench).  The sources of csrc/pinn_trunk_mfma.hip are written so that none is emitted (lin2,
-    fmac_bcast, slp_opaque); this compiles both translation units to assembly (no GPU needed) and looks."""
+    tools/opselbench; cause open: compiler or hardware, profiles/r03_packed_opsel.md).  The sources of
+    csrc/pinn_trunk_mfma.hip are written so that none is emitted (lin2, fmac_bcast, ring_splats), and since round 4
+    so are the exact-fp32 vector kernels of csrc/pinn_kernels.hip (bcast_elem in pinn_math.h); this compiles all three
+    translation units to assembly (no GPU needed) and looks."""
     import shutil
     import sys
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
@@ -191,6 +193,7 @@ def test_no_packed_opsel_forms_in_the_matrix_pipe_kernels():
     import opsel_check
     hits, tot = opsel_check.compile_and_scan()
     assert sum(tot.values()) > 10000          # the scan saw the kernels
+    assert any("7k_trunkI" in k for k in tot), "pinn_kernels.hip was not scanned"
     bad = {k: v for k, v in hits.items() if v}
     assert not bad, "packed op_sel forms in: %s" % sorted(bad)[:5]
     # and, while the assembly is at hand: the kernels of the benchmark's primary workload, of train.py's formulation

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """List packed-fp32 VALU instructions whose LOW result lane reads the HIGH dword of an operand pair
-(v_pk_{mul,fma,add}_f32 ... op_sel:[..1..]) per kernel of csrc/pinn_trunk_mfma.hip.
+(v_pk_{mul,fma,add}_f32 ... op_sel:[..1..]) per kernel of csrc/pinn_trunk_mfma.hip and csrc/pinn_kernels.hip.
 
     python tools/opsel_check.py [substring ...]
 
 Why: on MI355X these forms gave run-to-run different products in k_trunk2 when two workgroups shared a CU
 (profiles/r02_packed_opsel.md); the ring-fed arithmetic of the merged-pass kernels is written so that none is
-emitted there (lin2 / fmac_bcast in the source).  The tool compiles the translation unit to assembly (~40 s)."""
+emitted there (lin2 / fmac_bcast in the source; bcast_elem in pinn_math.h for the fp32 vector kernels, round 4).  The
+tool compiles the translation units to assembly (~60 s, in parallel)."""
 import collections
 import os
 import re
@@ -44,7 +45,7 @@ def compile_and_scan():
     with tempfile.TemporaryDirectory() as d:
         procs = []
         for objname, src, extra in UNITS:
-            if src != "pinn_trunk_mfma.hip":
+            if src not in ("pinn_trunk_mfma.hip", "pinn_kernels.hip"):
                 continue
             out = os.path.join(d, objname + ".s")
             procs.append((out, subprocess.Popen(

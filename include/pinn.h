@@ -103,6 +103,16 @@ int pinn_sample(pinn_handle *h, uint64_t seed, uint64_t step, const int32_t *ste
                 float bc_cutoff, float *x, float *y, float *z, float *R, uint8_t *mask,
                 int64_t *counts, void *stream);
 
+/* pinn_sample for a rank of a data-parallel job (the reference is single device: nothing to cite beyond
+ * pinn_sample's lines): counts_f32 (device float[2], may be NULL) also receives the two set sizes as floats --
+ * exact below 2^24 -- so that the caller can point it at the two spare floats behind its [grad | loss terms]
+ * message and all-reduce the sizes of the batch it has drawn ahead together with the gradient, without a
+ * conversion kernel of its own (pinn_adam_dp turns the summed floats back into int64). */
+int pinn_sample_dp(pinn_handle *h, uint64_t seed, uint64_t step, const int32_t *step_dev,
+                   int64_t first, int64_t n, float box, float Rlo, float Rhi, float cutoff,
+                   float bc_cutoff, float *x, float *y, float *z, float *R, uint8_t *mask,
+                   int64_t *counts, float *counts_f32, void *stream);
+
 /* Replaces NN_ion.forward + lapl/hamiltonian (poc/main.py:247-267,82-120,345)
  * and train.py:41-54 evaluated without a graph.  Outputs (each n floats, any
  * may be NULL): psi, E, lap = Laplacian(psi), res (the PDE residual; the
@@ -156,6 +166,15 @@ int pinn_residual_fwd_bwd(pinn_handle *h, const float *theta, const float *x, co
 int pinn_adam(pinn_handle *h, float *theta, const float *grad, float *m, float *v,
               int32_t *step_count, double lr, double beta1, double beta2, double eps,
               uint64_t trainable_mask, float *best_theta, float *best_loss, void *stream);
+
+/* pinn_adam for a rank of a data-parallel job: the step that consumes the all-reduced message also stores its two
+ * trailing floats (msg_counts: the global boundary-set sizes of the batch drawn ahead, summed over ranks; exact
+ * below 2^24) as int64 in counts_out, where the next pinn_residual_fwd_bwd takes them as bc_counts.  Both may be
+ * NULL (then identical to pinn_adam). */
+int pinn_adam_dp(pinn_handle *h, float *theta, const float *grad, float *m, float *v,
+                 int32_t *step_count, double lr, double beta1, double beta2, double eps,
+                 uint64_t trainable_mask, float *best_theta, float *best_loss,
+                 const float *msg_counts, int64_t *counts_out, void *stream);
 
 /* ---- measurement --------------------------------------------------------- */
 /* With nslots > 0, every pinn_residual_fwd_bwd call brackets its dominant

@@ -26,22 +26,30 @@ def simpson_weights(x):
 _GRID_CACHE = {}
 
 
-def _grid(params, n_test, device):
-    """linear grid of sampling(..., linearSampling=True) (poc/main.py:133-140,442-449), built on `device`;
-    the axes, the three Simpson weight vectors (fp64) and the flattened fp32 coordinates are cached per
-    (box, n_test, device): calculate_E_R asks for the same grid 39 times."""
+def clear_grid_cache():
+    _GRID_CACHE.clear()
+
+
+def _grid(params, n_test, device, points=True):
+    """linear grid of sampling(..., linearSampling=True) (poc/main.py:133-140,442-449), built on `device`.
+    Cached per (box, n_test, device): only what is O(n_test) -- the three axes (fp64, host) and the three Simpson
+    weight vectors (fp64, device; scipy's rule costs a host round trip, and calculate_E_R asks for the same grid 39
+    times).  The flattened fp32 coordinates (3 x 62 MB at n_test = 250) are rebuilt on the device per call: a
+    meshgrid is no work for it, the cache pins no bulk memory, and no caller can corrupt a later call's points."""
     key = (tuple(float(params[k + s]) for k in "xyz" for s in "LR"), int(n_test), str(device))
     hit = _GRID_CACHE.get(key)
     if hit is None:
         ax = [torch.linspace(params[k + "L"], params[k + "R"], n_test, dtype=torch.float64) for k in "xyz"]
         w = [torch.tensor(simpson_weights(a.numpy()), device=device, dtype=torch.float64) for a in ax]
-        axd = [a.to(device) for a in ax]
-        xg, yg, zg = torch.meshgrid(*axd, indexing="ij")
-        pts = [t.reshape(-1).to(torch.float32) for t in (xg, yg, zg)]
-        if len(_GRID_CACHE) >= 4:
+        if len(_GRID_CACHE) >= 8:
             _GRID_CACHE.clear()
-        hit = _GRID_CACHE[key] = (ax, w, pts)
-    return hit
+        hit = _GRID_CACHE[key] = (ax, w)
+    ax, w = hit
+    if not points:
+        return ax, w, None
+    xg, yg, zg = torch.meshgrid(*[a.to(device) for a in ax], indexing="ij")
+    pts = [t.reshape(-1).to(torch.float32) for t in (xg, yg, zg)]
+    return ax, w, pts
 
 
 def _integrate(model, w, u, v=None):
@@ -83,7 +91,7 @@ def energy_from_psi_LCAO(Ri, params, device=None):
     n = int(params["n_test"])
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
-    ax, w, _ = _grid(params, n, device)
+    ax, w, _ = _grid(params, n, device, points=False)
     xg, yg, zg = torch.meshgrid(*[a.to(device) for a in ax], indexing="ij")   # fp64: this curve is a closed form
     r1 = torch.sqrt((xg - Ri) ** 2 + yg ** 2 + zg ** 2)
     r2 = torch.sqrt((xg + Ri) ** 2 + yg ** 2 + zg ** 2)

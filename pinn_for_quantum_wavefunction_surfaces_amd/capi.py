@@ -14,7 +14,7 @@ PINN_PREC_F32, PINN_PREC_BF16, PINN_PREC_BF16X3 = 0, 1, 2
 
 EXPORTS = ["pinn_param_count", "pinn_tensor_count", "pinn_tensor_layout", "pinn_strerror",
            "pinn_create", "pinn_destroy", "pinn_last_error", "pinn_sample", "pinn_forward",
-           "pinn_residual_fwd_bwd", "pinn_adam", "pinn_profile_enable", "pinn_profile_read",
+           "pinn_residual_fwd_bwd", "pinn_adam", "pinn_sample_dp", "pinn_adam_dp", "pinn_profile_enable", "pinn_profile_read",
            "pinn_energy_R", "pinn_quadrature3d", "pinn_xchg_create", "pinn_xchg_local_handle", "pinn_xchg_connect",
            "pinn_xchg_allreduce", "pinn_xchg_set_timeout", "pinn_xchg_status", "pinn_xchg_destroy", "pinn_xchg_last_error"]
 
@@ -65,12 +65,15 @@ def load_library():
     lib.pinn_last_error.argtypes = [vp]
     lib.pinn_sample.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_int64, C.c_int64] + \
         [C.c_float] * 5 + [fp] * 4 + [vp, i64p, vp]
+    lib.pinn_sample_dp.argtypes = [vp, C.c_uint64, C.c_uint64, vp, C.c_int64, C.c_int64] + \
+        [C.c_float] * 5 + [fp] * 4 + [vp, i64p, fp, vp]
     lib.pinn_forward.argtypes = [vp] + [fp] * 5 + [C.c_int64, C.POINTER(Ham)] + [fp] * 4 + [vp]
     lib.pinn_energy_R.argtypes = [vp, fp, fp, C.c_int64, fp, fp, fp, vp]
     lib.pinn_quadrature3d.argtypes = [vp, fp, fp, fp, fp, fp, C.c_int64, C.c_int64, C.c_int64, fp, fp, vp]
     lib.pinn_residual_fwd_bwd.argtypes = [vp] + [fp] * 5 + [vp, C.c_int64, C.POINTER(Ham), i64p,
                                                              C.c_uint64, fp, vp]
     lib.pinn_adam.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_double] * 4 + [C.c_uint64, fp, fp, vp]
+    lib.pinn_adam_dp.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_double] * 4 + [C.c_uint64, fp, fp, fp, i64p, vp]
     lib.pinn_profile_enable.argtypes = [vp, C.c_int]
     lib.pinn_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     lib.pinn_xchg_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(vp)]
@@ -150,10 +153,11 @@ class Handle:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def sample(self, seed, step, first, n, box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
-               counts, step_dev=None):
-        self._check(self.lib.pinn_sample(self.h, seed, step, _ptr(step_dev), first, n, box, Rlo, Rhi, cutoff,
-                                         bc_cutoff, _ptr(x), _ptr(y), _ptr(z), _ptr(R), _ptr(mask),
-                                         _ptr(counts), self._stream()), "pinn_sample")
+               counts, step_dev=None, counts_f32=None):
+        """counts_f32 (float[2], optional): the set sizes as floats as well (pinn_sample_dp)"""
+        self._check(self.lib.pinn_sample_dp(self.h, seed, step, _ptr(step_dev), first, n, box, Rlo, Rhi, cutoff,
+                                            bc_cutoff, _ptr(x), _ptr(y), _ptr(z), _ptr(R), _ptr(mask),
+                                            _ptr(counts), _ptr(counts_f32), self._stream()), "pinn_sample_dp")
 
     def forward(self, theta, x, y, z, R, n, ham, psi=None, E=None, lap=None, res=None):
         self._check(self.lib.pinn_forward(self.h, _ptr(theta), _ptr(x), _ptr(y), _ptr(z), _ptr(R),
@@ -188,11 +192,14 @@ class Handle:
         return float(ms.value)
 
     def adam(self, theta, grad, m, v, step_count, lr, b1, b2, eps, trainable_mask,
-             best_theta=None, best_loss=None):
-        self._check(self.lib.pinn_adam(self.h, _ptr(theta), _ptr(grad), _ptr(m), _ptr(v),
-                                       _ptr(step_count), lr, b1, b2, eps,
-                                       C.c_uint64(trainable_mask), _ptr(best_theta),
-                                       _ptr(best_loss), self._stream()), "pinn_adam")
+             best_theta=None, best_loss=None, msg_counts=None, counts_out=None):
+        """msg_counts (float[2]) / counts_out (int64[2]), optional: pinn_adam_dp's conversion of the summed
+        boundary-set sizes that travelled behind the gradient message"""
+        self._check(self.lib.pinn_adam_dp(self.h, _ptr(theta), _ptr(grad), _ptr(m), _ptr(v),
+                                          _ptr(step_count), lr, b1, b2, eps,
+                                          C.c_uint64(trainable_mask), _ptr(best_theta),
+                                          _ptr(best_loss), _ptr(msg_counts), _ptr(counts_out), self._stream()),
+                    "pinn_adam_dp")
 
 
 XCHG_HANDLE_BYTES = 64

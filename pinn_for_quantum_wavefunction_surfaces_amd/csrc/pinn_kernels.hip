@@ -808,7 +808,9 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
                                                uint64_t trainable_mask,
                                                float* __restrict__ best_theta,
                                                float* __restrict__ best_loss,
-                                               unsigned* __restrict__ ticket)
+                                               unsigned* __restrict__ ticket,
+                                               const float* __restrict__ msg_counts,
+                                               long long* __restrict__ counts_out)
 {
     // the bias corrections are formed in double and rounded once, as torch does for fp32 tensors -- by ONE
     // thread per block (two double pow() per thread were most of this kernel's 10 us), handed out through LDS
@@ -847,6 +849,10 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
             *ticket = 0;                                 // for the next call
             *step_count = step;
             if (better) *best_loss = ltot;
+            if (msg_counts && counts_out) {              // data parallel: set sizes of the batch drawn ahead
+                counts_out[0] = (long long)msg_counts[0];
+                counts_out[1] = (long long)msg_counts[1];
+            }
         }
     }
 }
@@ -881,7 +887,8 @@ __global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t
                                                    float* __restrict__ z, float* __restrict__ R,
                                                    uint8_t* __restrict__ mask,
                                                    unsigned long long* __restrict__ counts,
-                                                   unsigned long long* __restrict__ part)
+                                                   unsigned long long* __restrict__ part,
+                                                   float* __restrict__ counts_f)
 {
     const uint64_t step = step0 + (step_dev ? (uint64_t)(int64_t)*step_dev : 0);
     const float two_box = box + box, dR = Rhi - Rlo;
@@ -911,7 +918,7 @@ __global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t
         c1 += mk & 1;
         c2 += (mk >> 1) & 1;
     }
-    if (counts) {
+    if (counts || counts_f) {
         // per-block partial counts, summed by whichever block finishes last (ticket): no memset of the counts
         // before the kernel (a 5 us node of its own in every step), no atomics on them; integer sums, so the
         // result does not depend on the order
@@ -947,8 +954,8 @@ __global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t
                 s2 += (unsigned long long)__shfl_xor((long long)s2, off, kWave);
             }
             if (threadIdx.x == 0) {
-                counts[0] = s1;
-                counts[1] = s2;
+                if (counts) { counts[0] = s1; counts[1] = s2; }
+                if (counts_f) { counts_f[0] = (float)s1; counts_f[1] = (float)s2; }
                 *reinterpret_cast<unsigned*>(part + 2 * kSampleMaxBlocks) = 0;   // ticket for the next call
             }
         }
@@ -1546,9 +1553,10 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     return PINN_OK;
 }
 
-extern "C" int pinn_adam(pinn_handle* h, float* theta, const float* grad, float* m, float* v,
-                         int32_t* step_count, double lr, double beta1, double beta2, double eps,
-                         uint64_t trainable_mask, float* best_theta, float* best_loss, void* stream)
+extern "C" int pinn_adam_dp(pinn_handle* h, float* theta, const float* grad, float* m, float* v,
+                            int32_t* step_count, double lr, double beta1, double beta2, double eps,
+                            uint64_t trainable_mask, float* best_theta, float* best_loss,
+                            const float* msg_counts, int64_t* counts_out, void* stream)
 {
     if (!h) return PINN_ERR_ARG;
     if (!theta || !grad || !m || !v || !step_count) return fail(h, PINN_ERR_ARG, "null pointer");
@@ -1556,9 +1564,35 @@ extern "C" int pinn_adam(pinn_handle* h, float* theta, const float* grad, float*
     hipLaunchKernelGGL(k_adam, dim3(blocks < kAdamMaxBlocks ? blocks : kAdamMaxBlocks), dim3(1024), 0,
                        (hipStream_t)stream, theta, grad, m, v, step_count, h->P, lr, beta1, beta2, eps,
                        h->tensor_of, trainable_mask, best_theta, best_loss,
-                       reinterpret_cast<unsigned*>(h->samp + 2 * kSampleMaxBlocks + 1));
+                       reinterpret_cast<unsigned*>(h->samp + 2 * kSampleMaxBlocks + 1), msg_counts,
+                       reinterpret_cast<long long*>(counts_out));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_adam", e);
+    return PINN_OK;
+}
+
+extern "C" int pinn_adam(pinn_handle* h, float* theta, const float* grad, float* m, float* v,
+                         int32_t* step_count, double lr, double beta1, double beta2, double eps,
+                         uint64_t trainable_mask, float* best_theta, float* best_loss, void* stream)
+{
+    return pinn_adam_dp(h, theta, grad, m, v, step_count, lr, beta1, beta2, eps, trainable_mask, best_theta, best_loss,
+                        nullptr, nullptr, stream);
+}
+
+extern "C" int pinn_sample_dp(pinn_handle* h, uint64_t seed, uint64_t step, const int32_t* step_dev,
+                              int64_t first, int64_t n, float box, float Rlo, float Rhi, float cutoff,
+                              float bc_cutoff, float* x, float* y, float* z, float* R, uint8_t* mask,
+                              int64_t* counts, float* counts_f32, void* stream)
+{
+    if (!h) return PINN_ERR_ARG;
+    if (!x || !y || !z || !R || n < 1 || first < 0) return fail(h, PINN_ERR_ARG, "null pointer or bad range");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t sblocks = (n + kSampleBlock - 1) / kSampleBlock;
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)(sblocks < kSampleMaxBlocks ? sblocks : kSampleMaxBlocks)), dim3(kSampleBlock), 0, st,
+                       seed, step, step_dev, first, n, box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
+                       (unsigned long long*)counts, h->samp, counts_f32);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_sample", e);
     return PINN_OK;
 }
 
@@ -1567,14 +1601,6 @@ extern "C" int pinn_sample(pinn_handle* h, uint64_t seed, uint64_t step, const i
                            float bc_cutoff, float* x, float* y, float* z, float* R, uint8_t* mask,
                            int64_t* counts, void* stream)
 {
-    if (!h) return PINN_ERR_ARG;
-    if (!x || !y || !z || !R || n < 1 || first < 0) return fail(h, PINN_ERR_ARG, "null pointer or bad range");
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t sblocks = (n + kSampleBlock - 1) / kSampleBlock;
-    hipLaunchKernelGGL(k_sample, dim3((unsigned)(sblocks < kSampleMaxBlocks ? sblocks : kSampleMaxBlocks)), dim3(kSampleBlock), 0, st,
-                       seed, step, step_dev, first, n, box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask,
-                       (unsigned long long*)counts, h->samp);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_sample", e);
-    return PINN_OK;
+    return pinn_sample_dp(h, seed, step, step_dev, first, n, box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask, counts,
+                          nullptr, stream);
 }

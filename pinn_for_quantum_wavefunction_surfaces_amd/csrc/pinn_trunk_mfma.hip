@@ -4143,12 +4143,19 @@ bool mfma_x3_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 |
 
 // resident blocks per CU the chosen decomposition is built for (pinn_create sizes the persistent
 // grid and the per-block partial buffer with it)
-// measurement switch (tools/kbench.py): PINN_MFMA_VARIANT = 0 (default) or 3 (the per-pass kernel
-// k_trunk_mfma2 where k_trunk2 is the default); read at every launch
+// measurement switch (tools/kbench.py): PINN_MFMA_VARIANT = 0 (default), 3 (the per-pass kernel k_trunk_mfma2 where a
+// merged-pass kernel is the default) or 11.. (variants of k_trunkD).  Read ONCE per process (round 4; it was a getenv per
+// launch) -- except under PINN_MFMA_VARIANT_LIVE=1, which tools/kbench.py and the tests set to switch variants inside
+// one process.
 static int mfma_variant()
 {
-    const char* e = getenv("PINN_MFMA_VARIANT");
-    return (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 0;
+    auto read = [] {
+        const char* e = getenv("PINN_MFMA_VARIANT");
+        return (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : 0;
+    };
+    static const bool live = [] { const char* e = getenv("PINN_MFMA_VARIANT_LIVE"); return e && e[0] == '1'; }();
+    static const int once = read();
+    return live ? read() : once;
 }
 
 int mfma_blocks_per_cu(int H, int L, bool x3)

@@ -44,7 +44,14 @@ struct PeerTable {
 };
 
 // state[0] calls completed (= seq of the last one), state[1] blocks of the running sum kernel that are
-// done, state[2] 1 after a timed-out wait (sticky)
+// done, state[2] sticky status: 1 after a timed-out wait, 2 after a sum that was not finite (a peer that timed out
+// earlier pushes the NaN message it was left with, so its partners learn of it with the next call; a diverged
+// gradient reports the same way), state[3] this call's decision, taken ONCE for all blocks of the sum kernel (0
+// undecided, 1 every peer arrived, 2 timed out): the first block through its wait publishes it, the others follow
+// it, so a peer that arrives right at the deadline cannot leave buf part sum, part NaN.
+// What status() does NOT prove: a rank whose own waits all succeeded has state[2] == 0 even if a PEER timed out on
+// that same call (the peer computed NaN, this rank a valid sum: the replicas differ until the next call's non-finite
+// sum flags it here too); a caller that needs agreement at a given step checks after the following call.
 __global__ __launch_bounds__(kPushThreads) void k_xchg_push(PeerTable T, const float* __restrict__ buf, int64_t n,
                                                            int64_t cap, int me, int world,
                                                            const unsigned* __restrict__ state)
@@ -86,8 +93,11 @@ __global__ __launch_bounds__(kSumThreads) void k_xchg_sum(const float* __restric
                 __builtin_amdgcn_s_sleep(8);
             }
         }
-        ok = good;
-        if (!good) atomicExch(state + 2, 1u);   // a peer never arrived: report, and poison buf below
+        // one decision per call: whoever gets here first publishes it, everybody follows it
+        const unsigned mine = good ? 1u : 2u;
+        const unsigned prev = atomicCAS(state + 3, 0u, mine);
+        ok = (prev ? prev : mine) == 1u;
+        if (!ok) atomicCAS(state + 2, 0u, 1u);  // a peer never arrived: report, and poison buf below
     }
     __syncthreads();
     const unsigned seq = seq_s;
@@ -100,6 +110,7 @@ __global__ __launch_bounds__(kSumThreads) void k_xchg_sum(const float* __restric
             float s = __builtin_nontemporal_load(base + i);
             for (int q = 1; q < world; q++) s += __builtin_nontemporal_load(base + (size_t)q * cap + i);
             buf[i] = s;
+            if (!(__builtin_fabsf(s) <= 3.402823466e38f)) atomicCAS(state + 2, 0u, 2u);   // NaN or inf: see state[2]
         }
     } else {
         // no silent local-only gradient: whatever consumes buf (loss terms, Adam) sees NaN
@@ -112,6 +123,7 @@ __global__ __launch_bounds__(kSumThreads) void k_xchg_sum(const float* __restric
         __threadfence();
         if (atomicAdd(state + 1, 1u) == gridDim.x - 1) {     // last block of this call
             __hip_atomic_store(state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(state + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next call: undecided
             __hip_atomic_store(state, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -126,7 +138,7 @@ struct pinn_xchg {
     size_t recv_bytes, flag_bytes;
     void* mapped[kMaxWorld];     // peers' allocations as mapped here (own: == local)
     PeerTable table;
-    unsigned* state;             // device words: [0] calls completed, [1] sum blocks done, [2] timed out
+    unsigned* state;             // device words: [0] calls completed, [1] sum blocks done, [2] status, [3] decision
     bool connected;
     double timeout_s;
     char err[256];
@@ -250,7 +262,9 @@ extern "C" int pinn_xchg_status(pinn_xchg* x, void* stream)
     unsigned s = 0;
     XCHK(x, hipMemcpyAsync(&s, x->state + 2, sizeof s, hipMemcpyDeviceToHost, (hipStream_t)stream));
     XCHK(x, hipStreamSynchronize((hipStream_t)stream));
-    if (s) return xfail(x, PINN_ERR_HIP, "a peer did not arrive within the exchange timeout");
+    if (s == 1) return xfail(x, PINN_ERR_HIP, "a peer did not arrive within the exchange timeout");
+    if (s) return xfail(x, PINN_ERR_HIP, "an exchanged sum was not finite (a peer that timed out earlier pushed its NaN "
+                                         "message, or the gradient itself diverged)");
     return PINN_OK;
 }
 

@@ -68,13 +68,18 @@ def train(params, lr, epochs, n=None, Rlo=None, Rhi=None, L=None, cutoff=None, b
     tr = Trainer(model, p, n_points=n, lr=lr, seed=seed, device=device)
     hist = torch.zeros(epochs, 3, device=tr.device, dtype=torch.float32)
     best = torch.zeros(epochs, device=tr.device, dtype=torch.float32)
+    e_buf = torch.empty(n, device=tr.device, dtype=torch.float32) if verbose else None
     for tt in range(epochs):
+        show = verbose and tt % 10 == 0
+        theta_eval = tr.theta.clone() if show else None  # the parameters this pass's loss is evaluated at
         tr.step(resample=True, track_best=True)          # sc_sampling = 1; best tracked from step 0
         hist[tt].copy_(tr.grad[tr.P:])
         best[tt:tt + 1].copy_(tr.best_loss)
-        if verbose and tt % 10 == 0:                     # train.py:61-64 (this one synchronises)
+        if show:                                         # train.py:61-64: Ltot Lpde Lbc (mean(e)) [Lbest]; synchronises
+            tr.h.forward(theta_eval, tr.x, tr.y, tr.z, tr.R, n, model.ham(), E=e_buf)
             l = hist[tt].tolist()
-            print("%8d: %.2e %.2e %.2e [%.5e]" % (tt, sum(l), l[0], l[1] + l[2], float(best[tt])))
+            print("%8d: %.2e %.2e %.2e (%.2e) [%.5e]" % (tt, sum(l), l[0], l[1] + l[2], float(e_buf.mean()),
+                                                        float(best[tt])))
     tr.evaluate(resample=True, track_best=True)          # train.py:24-69: pass epochs + 1 only evaluates,
     torch.cuda.synchronize()                             # so the final parameters can become the best
     tr.sync_to_model(best=True)                          # train.py:65-69

@@ -198,8 +198,8 @@ class NN_ion(nn.Module):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         h = self._handles.get(idx)
         if h is None or h.max_points < n:
-            if h is not None:
-                h.close()
+            # a larger workspace is a NEW handle; the old one is only let go of here, never closed: a Trainer (or any
+            # other caller) may still hold it, and it is destroyed when its last reference goes (Handle.__del__)
             h = capi.Handle(self._arch, idx, max(int(n), 4096))
             self._handles[idx] = h
         return h

@@ -8,8 +8,10 @@ the only exchanged data are SUMs, of
   * one flat fp32 buffer [grad(P) | Lpde, Lbc1, Lbc2] after the fused kernel
     (already scaled with global 1/N), after which every rank runs the same Adam.
 The Trainer sends both in ONE all-reduce per step: the next batch is sampled while
-the current step runs and its set sizes ride behind the gradient as two floats
-(exact below 2^24 points; above that, or for a one-off batch, reduce_counts is used).
+the current step runs and its set sizes ride behind the gradient as two floats -- written there by the
+sampler itself (pinn_sample_dp) and turned back into int64 by the Adam kernel that consumes the message
+(pinn_adam_dp), so the step contains no conversion kernels (exact below 2^24 points; above that, or for a
+one-off batch, reduce_counts is used).
 The backend is whatever torch.distributed was initialised with ("nccl" = RCCL over
 xGMI on MI355X; "gloo" in the CPU tests).  With world_size 1 nothing is called.
 
@@ -95,12 +97,24 @@ class DataParallelPlan:
     def invN(self):
         return 1.0 / self.n_global
 
-    def reduce_counts(self, counts):
-        """int64[2] BC set sizes: local -> global (in place)."""
+    def counts_f32(self):
+        """one-shot path below 2^24 global points: the float[2] buffer pinn_sample_dp writes the local set sizes
+        into, so that reduce_counts needs no conversion kernels before the exchange (None otherwise)"""
+        if self._xchg is not None and self.n_global < (1 << 24):
+            return self._cnt_f[:2]
+        return None
+
+    def reduce_counts(self, counts, counts_f32=None):
+        """int64[2] BC set sizes: local -> global (in place).  counts_f32: the same local sizes as floats, already
+        written by the sampler (see counts_f32())."""
         if not self.collectives:
             return counts
-        if self._xchg is not None:
-            # 16-bit pieces as floats: sums over <= 16 ranks stay below 2^24, i.e. exact in fp32
+        if self._xchg is not None and counts_f32 is not None:
+            self._xchg.allreduce(counts_f32)           # integers below 2^24: exact in fp32, on every rank alike
+            counts.copy_(counts_f32)
+        elif self._xchg is not None:
+            # 2^24 points and more: 16-bit pieces as floats, sums over <= 256 ranks stay below 2^24, i.e. exact in
+            # fp32 (the exchange itself takes at most kMaxWorld = 16 ranks)
             self._cnt_f.copy_(torch.bitwise_and(counts[:, None] >> self._shifts, 0xFFFF).reshape(8))
             self._xchg.allreduce(self._cnt_f)
             counts.copy_((self._cnt_f.reshape(2, 4).to(torch.int64) << self._shifts).sum(1))
@@ -114,14 +128,20 @@ class DataParallelPlan:
             self._sum(buf)
         return buf
 
-    def reduce_grad_and_counts(self, buf, counts_local, counts_global):
-        """One message for both exchanges: buf = fp32[P+5] = [grad | three loss terms | 2 spare];
-        counts_local (int64[2], the NEXT batch's local BC set sizes) travel in the two spare
-        floats and come back summed in counts_global (int64[2]).  Needs n_global < 2^24."""
+    def reduce_message(self, buf):
+        """One message for both exchanges: buf = fp32[P+5] = [grad | three loss terms | the NEXT batch's two local
+        BC set sizes, written there as floats by pinn_sample_dp]; comes back summed.  pinn_adam_dp stores the two
+        summed sizes as int64 for the next pinn_residual_fwd_bwd.  Needs n_global < 2^24 (exact in fp32)."""
         assert self.n_global < (1 << 24)
-        buf[-2:].copy_(counts_local)            # int64 -> fp32 inside the copy kernel (exact < 2^24)
         if self.collectives:
             self._sum(buf)
+        return buf
+
+    def reduce_grad_and_counts(self, buf, counts_local, counts_global):
+        """reduce_message with the conversions done by torch copies (round 3's form; kept for callers that hold the
+        local sizes as int64): counts_local travel in the two spare floats, come back summed in counts_global."""
+        buf[-2:].copy_(counts_local)            # int64 -> fp32 inside the copy kernel (exact < 2^24)
+        self.reduce_message(buf)
         counts_global.copy_(buf[-2:])           # sums of integers below 2^24 are exact in fp32
         return buf
 

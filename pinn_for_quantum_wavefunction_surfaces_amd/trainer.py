@@ -76,7 +76,6 @@ class Trainer:
         self._pts = [[torch.empty(self.n, device=dev, dtype=f32) for _ in range(4)] +
                      [torch.empty(self.n, device=dev, dtype=torch.uint8)] for _ in range(2)]
         self._cnt = [torch.zeros(2, device=dev, dtype=torch.int64) for _ in range(2)]  # GLOBAL sizes
-        self._cnt_local = torch.zeros(2, device=dev, dtype=torch.int64)
         self._cur = 0
         self.tmask = model.trainable_mask()
         self.t = 0
@@ -100,20 +99,21 @@ class Trainer:
     mask = property(lambda self: self._pts[self._cur][4])
     counts = property(lambda self: self._cnt[self._cur])
 
-    def _sample_into(self, buf, counts_out, step, ahead):
+    def _sample_into(self, buf, counts_out, step, ahead, counts_f32=None):
         p = self.params
         x, y, z, R, mask = self._pts[buf]
         self.h.sample(self.seed, ahead if step is None else step, self.plan.first, self.n,
                       float(p["xR"]), float(p["RxL"]), float(p["RxR"]), float(p["cutOff"]),
                       float(p["BCcutoff"]), x, y, z, R, mask, counts_out,
-                      step_dev=self.step_count if step is None else None)
+                      step_dev=self.step_count if step is None else None, counts_f32=counts_f32)
 
     def resample(self, step=None):
         """Draw this rank's points of Philox step `step` into the current buffer and make their
         global boundary-set sizes available; by default the step is the device-side Adam step
         counter (so a captured graph of step() draws fresh points on every replay)."""
-        self._sample_into(self._cur, self._cnt[self._cur], step, 0)
-        self.plan.reduce_counts(self._cnt[self._cur])
+        cf = self.plan.counts_f32()                 # one-shot exchange: the sampler writes the floats it sends
+        self._sample_into(self._cur, self._cnt[self._cur], step, 0, counts_f32=cf)
+        self.plan.reduce_counts(self._cnt[self._cur], counts_f32=cf)
         self._sampled = True
 
     def capture_graph(self, resample=True, track_best=True, warmup=3):
@@ -158,10 +158,14 @@ class Trainer:
         k = int(next_resample or 0)
         # points of step t + k and their local counts -- unless an earlier step already drew them (with
         # sc_sampling > 1 the driver hints at the same step twice: at the resampling step and at t+k-1)
+        msg = {}
         if self.pipelined and k >= 1 and self._ahead_for != self.t + k:
-            self._sample_into(1 - cur, self._cnt_local, None, k)
-            # ONE message: [grad | losses | that batch's counts]
-            self.plan.reduce_grad_and_counts(self.gbuf, self._cnt_local, self._cnt[1 - cur])
+            # ONE message: [grad | losses | that batch's local set sizes], the sizes written as floats behind the
+            # loss terms by the sampler; the Adam kernel below stores their sums as int64 for the step that
+            # trains on that batch -- no conversion kernels in between
+            self._sample_into(1 - cur, None, None, k, counts_f32=self.gbuf[self.P + 3:])
+            self.plan.reduce_message(self.gbuf)
+            msg = dict(msg_counts=self.gbuf[self.P + 3:], counts_out=self._cnt[1 - cur])
             self._ahead_for = self.t + k
         else:
             self.plan.reduce_grad(self.grad)
@@ -173,7 +177,7 @@ class Trainer:
             ltot = self.grad[self.P:].sum()
             better = ltot < self.best_loss
             self.h.adam(self.theta, self.grad, self.m, self.v, self.step_count, self.lr, self.b1,
-                        self.b2, self.eps, self.tmask, None, None)
+                        self.b2, self.eps, self.tmask, None, None, **msg)
             for dst, src in ((self.best_theta, self.theta), (self.best_m, self.m), (self.best_v, self.v),
                              (self.best_step, self.step_count), (self.best_loss, ltot.reshape(1))):
                 torch.where(better, src, dst, out=dst)
@@ -181,7 +185,7 @@ class Trainer:
             self.h.adam(self.theta, self.grad, self.m, self.v, self.step_count, self.lr, self.b1,
                         self.b2, self.eps, self.tmask,
                         self.best_theta if track_best else None,
-                        self.best_loss if track_best else None)
+                        self.best_loss if track_best else None, **msg)
         self.t += 1
 
     def evaluate(self, resample=True, track_best=True):

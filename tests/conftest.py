@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the kernel-variant switch is read once per process by the library; the tests flip it between calls
+os.environ.setdefault("PINN_MFMA_VARIANT_LIVE", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -7,6 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("PINN_MFMA_VARIANT_LIVE", "1")   # variants are switched inside this process
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -1653,8 +1653,13 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert rf["kernel_ms"] <= d["ms_per_step"]       # the dominant kernel fits inside the step
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
-    po = d["parity_observed"]
+    for leg in ("n4000", "n4000_2x64tanh_trainpy", "n1000000_chunked"):     # SURVEY 8(d)'s other batch sizes
+        assert cb[leg]["value"] > 0 and cb[leg]["steps"] >= 1
+    po = d["parity_observed"]["farther_than_0.25_au"]
     assert po["psi"] < 1e-2 and po["E"] < 1e-5 and po["grad"] < 3e-2
+    pa = d["parity_observed"]["all_points"]                # near-nucleus points included: reported, psi and E still held
+    assert pa["points"] == 16384 and pa["psi"] < 1e-2 and pa["E"] < 1e-5 and np.isfinite(pa["grad"])
+    assert "traffic" in rf and "traffic_source" in rf
 
 
 def test_bench_starts_its_own_ranks_two_on_one_gpu():
@@ -1668,6 +1673,13 @@ def test_bench_starts_its_own_ranks_two_on_one_gpu():
                     {"PINN_REHEARSE_ONE_GPU": "1"})
     assert d1["config"]["exchange"].startswith("one-shot") and d1["config"]["exchange_status"] == "ok"
     assert np.isfinite(d1["loss"]["Ltot"])
+    # the N > 1 branch with the whole step captured into a HIP graph on the one-shot exchange (no torch.distributed
+    # call inside a step: the set sizes travel through the exchange as the floats the sampler wrote): same loss as the
+    # eager one-shot run after the same number of steps from the same seed
+    d2 = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "50000", "--one-shot", "--graph"],
+                    {"PINN_REHEARSE_ONE_GPU": "1"})
+    assert d2["config"]["exchange"].startswith("one-shot") and d2["config"]["exchange_status"] == "ok"
+    assert np.isfinite(d2["loss"]["Ltot"]) and d2["n_gpus"] == 2
 
 
 # ----------------------------------------------------------------------------- size sweep

@@ -93,7 +93,7 @@ class OracleHandle:
         self.calls = []
 
     def sample(self, seed, step, first, n, box, Rlo, Rhi, cutoff, bc_cutoff, x, y, z, R, mask, counts,
-               step_dev=None):
+               step_dev=None, counts_f32=None):
         st = int(step) + (int(step_dev.item()) if step_dev is not None else 0)
         self.calls.append(("sample", st))
         ox, oy, oz, oR, om, oc = self.O.sample(seed, st, first, n, box, Rlo, Rhi, cutoff, bc_cutoff)
@@ -101,6 +101,8 @@ class OracleHandle:
             dst.copy_(torch.from_numpy(src))
         if counts is not None:
             counts.copy_(torch.tensor(oc, dtype=torch.int64))
+        if counts_f32 is not None:                     # pinn_sample_dp: the same sizes as floats
+            counts_f32.copy_(torch.tensor(oc, dtype=torch.float32))
 
     def residual_fwd_bwd(self, theta, x, y, z, R, mask, n, ham, bc_counts, tmask, out):
         c = [int(v) for v in bc_counts.tolist()]
@@ -112,7 +114,10 @@ class OracleHandle:
         out.copy_(torch.tensor(np.concatenate([lg["grad"], [s[0] * ham.invN, s[1] / max(c[0], 1),
                                                             s[2] / max(c[1], 1)]]), dtype=torch.float32))
 
-    def adam(self, theta, grad, m, v, step_count, lr, b1, b2, eps, tmask, best_theta=None, best_loss=None):
+    def adam(self, theta, grad, m, v, step_count, lr, b1, b2, eps, tmask, best_theta=None, best_loss=None,
+             msg_counts=None, counts_out=None):
+        if msg_counts is not None and counts_out is not None:   # pinn_adam_dp: summed float sizes -> int64
+            counts_out.copy_(msg_counts.to(torch.int64))
         th, g, mm, vv = [t.numpy().astype(np.float64) for t in (theta, grad[:self.P], m, v)]
         step_count += 1
         self.O.adam(self.A, th, np.ascontiguousarray(g), mm, vv, int(step_count.item()), lr, b1, b2, eps,

@@ -1208,7 +1208,8 @@ struct T2Cfg {
     static_assert(OCC * LDS_BYTES <= 160 * 1024, "k_trunk2 does not fit the CU's LDS");
 };
 
-template <int H, int ACT>
+// SWZ: exchange slots of the odd lane groups permuted by c ^ 12 (see k_trunkD: conflict-free transposed reads)
+template <int H, int ACT, bool SWZ = true>
 __global__ __launch_bounds__(T2Cfg<H>::WAVES * 64, T2Cfg<H>::OCC * T2Cfg<H>::WAVES / 4)
 void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, TrunkArgs A)
 {
@@ -1231,8 +1232,11 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row tile owned by this wave
     const int g = lane >> 4, c = lane & 15;
     const int lane16 = lane * 16;
-    const int own_slot = lane16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
-    const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
+    auto slot16 = [](int gg, int cc) { return (gg * 16 + (SWZ ? (cc ^ ((gg & 1) * 12)) : cc)) * 16; };
+    const int sw16 = slot16(g, c);
+    const int own_slot = sw16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
+    const int trl = (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2)) + (c & 1) * 8;
+    const int trh = SWZ ? (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2) + 4) + (c & 1) * 8 : trl + 64;
     const int n0 = 16 * part + 4 * g;                                    // first own neuron of this lane
 
     {   // weights (fragment order) and small parameters -> LDS
@@ -1303,12 +1307,12 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + own_slot + s * 1024) = pack4(v);
     };
     auto bfrag = [&](lds_p eb, int kc, int s) {
-        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + lane16 + (kc * NST + s) * 1024);
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + sw16 + (kc * NST + s) * 1024);
     };
     auto trfrag = [&](lds_p eb, int T, int ph) {     // rows 32ph..32ph+31 of the [column][neuron] image, tile T
-        const lds_p p0 = eb + trl + ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 64));
+        const int o = ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trl + o));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trh + o));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
 
@@ -1556,7 +1560,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     if (threadIdx.x == 3) out[Lay::bout] = sc[3];
 }
 
-template <int H, int ACT>
+template <int H, int ACT, bool SWZ = true>
 hipError_t launch_trunk2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
 {
     using C1 = MCfg<H, 2>;
@@ -1565,7 +1569,7 @@ hipError_t launch_trunk2_t(const float* theta, __bf16* wpk, const TrunkArgs& A, 
     hipLaunchKernelGGL((k_pack_weights<H, 2, false>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    auto kern = k_trunk2<H, ACT>;
+    auto kern = k_trunk2<H, ACT, SWZ>;
     static bool attr_set[64] = {};   // per device (not a stream operation: done outside graph capture)
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1629,8 +1633,12 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row tile owned by this wave
     const int g = lane >> 4, c = lane & 15;
     const int lane16 = lane * 16;
-    const int own_slot = lane16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
-    const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
+    // exchange slots: the 16-byte slots of the odd lane groups permuted by c ^ 12 (k_trunkD: conflict-free transposed reads)
+    auto slot16 = [](int gg, int cc) { return (gg * 16 + (cc ^ ((gg & 1) * 12))) * 16; };
+    const int sw16 = slot16(g, c);
+    const int own_slot = sw16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
+    const int trl = (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2)) + (c & 1) * 8;
+    const int trh = (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2) + 4) + (c & 1) * 8;
     const int n0 = 16 * part + 4 * g;                                    // first own neuron of this lane
 
     {   // weights (fragment order) and small parameters -> LDS
@@ -1702,12 +1710,12 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + own_slot + s * 1024) = pack4(v);
     };
     auto bfrag = [&](lds_p eb, int kc, int s) {
-        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + lane16 + (kc * NST + s) * 1024);
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + sw16 + (kc * NST + s) * 1024);
     };
     auto trfrag = [&](lds_p eb, int T, int ph) {     // rows 32ph..32ph+31 of the [column][neuron] image, tile T
-        const lds_p p0 = eb + trl + ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 64));
+        const int o = ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trl + o));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trh + o));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
 
@@ -2081,8 +2089,12 @@ void k_trunk2x(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     const int grp = wave / C::WPG, part = wave % C::WPG;
     const int g = lane >> 4, c = lane & 15;
     const int lane16 = lane * 16;
-    const int own_slot = lane16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
-    const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
+    // exchange slots: the 16-byte slots of the odd lane groups permuted by c ^ 12 (k_trunkD: conflict-free transposed reads)
+    auto slot16 = [](int gg, int cc) { return (gg * 16 + (cc ^ ((gg & 1) * 12))) * 16; };
+    const int sw16 = slot16(g, c);
+    const int own_slot = sw16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
+    const int trl = (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2)) + (c & 1) * 8;
+    const int trh = (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2) + 4) + (c & 1) * 8;
     const int n0 = 16 * part + 4 * g;
     const lds_p gbase = lds0 + C::OFF_G + grp * C::GBYTES;
     const lds_p XB = gbase, YB = gbase + 2 * EB;
@@ -2153,12 +2165,12 @@ void k_trunk2x(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + EB1 + own_slot + s * 1024) = pl;
     };
     auto bfrag = [&](lds_p eb, int kc, int s) {
-        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + lane16 + (kc * NST + s) * 1024);
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + sw16 + (kc * NST + s) * 1024);
     };
     auto trfrag = [&](lds_p eb, int T, int ph) {
-        const lds_p p0 = eb + trl + ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 64));
+        const int o = ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trl + o));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trh + o));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
     // D[own 16 rows][2 passes x NST column tiles] += W x B with split operands: per (k chunk, pass) group the
@@ -3019,6 +3031,8 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int lane16 = lane * 16;
+    // (lane-linear exchange slots: the swizzle of the other merged-pass kernels costs this one a register it does not
+    // have -- 0.906 -> 0.946 ms per 100 000 points with it, A/B on one box, round 4)
     const int own_slot = lane16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
     const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
     const int n0 = 16 * part + 4 * g;
@@ -4212,6 +4226,12 @@ bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, cons
                                             : launch_trunk2s_t<64, ACT_SIGMOID>(theta, wpk, A, grid, st);
         else *err = act == ACT_TANH ? launch_trunk2s_t<128, ACT_TANH>(theta, wpk, A, grid, st)
                                     : launch_trunk2s_t<128, ACT_SIGMOID>(theta, wpk, A, grid, st);
+        return true;
+    }
+    if (L == 2 && npass == 2 && mode == MODE_BWD && mfma_variant() == 12 && act == ACT_TANH && (H == 64 || H == 128)) {
+        // measurement variant (tools/kbench.py): k_trunk2 with round 3's lane-linear exchange slots
+        *err = H == 64 ? launch_trunk2_t<64, ACT_TANH, false>(theta, wpk, A, grid, st)
+                       : launch_trunk2_t<128, ACT_TANH, false>(theta, wpk, A, grid, st);
         return true;
     }
     if (L == 2 && npass == 2 && mode == MODE_BWD && mfma_variant() != 3 && (H == 64 || H == 128)) {

@@ -46,7 +46,7 @@ class RoundedLinear(torch.autograd.Function):
         return dX, dW, None
 
 
-def loss_grad(g, cfg, sl=slice(None)):
+def loss_grad(g, cfg, sl=slice(None), want_fields=False):
     L, H = 4, 128
     th = torch.tensor(g["theta"], dtype=torch.float64)
     shapes = [(H, 2), (H,)] + [(H, H), (H,)] * (L - 1) + [(1, H), (1,), (32, 1), (32,), (32, 32), (32,), (1, 32), (1,),
@@ -100,7 +100,11 @@ def loss_grad(g, cfg, sl=slice(None)):
     m1, m2 = (mask & 1).double(), ((mask >> 1) & 1).double()
     Ltot = (res ** 2).mean() + (psi ** 2 * m1).sum() / m1.sum().clamp(min=1) + (psi ** 2 * m2).sum() / m2.sum().clamp(min=1)
     Ltot.backward()
-    return float(Ltot), np.concatenate([p.grad.numpy().ravel() for p in ps])
+    grad = np.concatenate([p.grad.numpy().ravel() for p in ps])
+    if want_fields:
+        f = lambda t: t.detach().numpy().ravel()
+        return float(Ltot.detach()), grad, dict(psi=f(psi), lap=f(lap), res=f(res))
+    return float(Ltot.detach()), grad
 
 
 def main():

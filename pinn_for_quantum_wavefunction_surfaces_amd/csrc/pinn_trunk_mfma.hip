@@ -2466,14 +2466,14 @@ struct TDCfg {
     static_assert(OFF_S % 16 == 0 && OFF_R % 16 == 0, "alignment");
 };
 
-// VAR (measurement variants, tools/kbench.py): bit 0 = exchange slots lane-linear (round 3's layout) instead of swizzled;
-// bit 1 = waves WAVES/2.. (the younger SIMD partners, which lose the age-based issue arbitration) at s_setprio 1;
-// bit 2 = every wave at s_setprio 2 for the first pass of a phase and 0 for the second (the partner that is behind wins).
+// VAR (measurement variant, tools/kbench.py): bit 0 = exchange slots lane-linear (round 3's layout) instead of swizzled.
+// (s_setprio variants -- the younger half of the block at priority 1; the halves leading one pass of a phase each -- measured
+// +0.8 % and +49 % in round 4 and removed: profiles/r04_trunkD_notes.md.)
 template <int H, int L, int ACT, int VAR = 0>
 __global__ __launch_bounds__((TDCfg<H, L>::WAVES * 64), (TDCfg<H, L>::OCC * TDCfg<H, L>::WAVES / 4))
 void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, uint4* __restrict__ stash_g, TrunkArgs A)
 {
-    constexpr bool SWZ = (VAR & 1) == 0, PRIO_STATIC = (VAR & 2) != 0, PRIO_DYN = (VAR & 4) != 0;
+    constexpr bool SWZ = (VAR & 1) == 0;
     using C = TDCfg<H, L>;
     using Lay = TrunkLayout<H, L>;
     constexpr int HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB, NW = C::NW;
@@ -2665,7 +2665,6 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
 #else
 #define TD_STAMP(i) do { } while (0)
 #endif
-    if (PRIO_STATIC && part >= C::WAVES / 2) __builtin_amdgcn_s_setprio(1);
     for (int64_t itx = 0; itx < iters; itx++) {
         const int64_t tile = itx * gridDim.x + blockIdx.x;
         const int64_t idx = tile * 16 + c;
@@ -2758,7 +2757,6 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             };
 #pragma unroll
             for (int ps = 0; ps < 2; ps++) {
-                if (PRIO_DYN) { if (ps == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
                 f32x4 acc[NST];
                 fwdG(ps, acc);
                 fwdE(ps, acc);
@@ -2826,7 +2824,6 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                     for (int ps = 0; ps < 2; ps++) { sq[ps][0] = stash_get(l - 1, 2 * ps); sq[ps][1] = stash_get(l - 1, 2 * ps + 1); }
                 }
             }
-            if (PRIO_DYN) __builtin_amdgcn_s_setprio(2);
             wgrad(wacc[l - 1], YB, Xin);
             u32x2 yp[2][NST];               // adjoints of layer l-1, packed: written to YB once every wave has read it
             float inA[2][NST];
@@ -2842,7 +2839,6 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
                 f32x4 ob[NST];
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
-                if (PRIO_DYN && ps == 1) __builtin_amdgcn_s_setprio(0);
                 gemmP(afr, YB + ps * EB, ob);
                 if (ps == 1) {
                     // next A fragments: the transposed matrix of layer l-1, or layer 1 forward for the next tile
@@ -4273,13 +4269,9 @@ bool launch_trunk_mfma_128x4(int act, int npass, int mode, bool x3, int variant,
               // layer-output buffer (XONE)
         return launch2_HL<128, 4, 4, 4, true, 0>(act, npass, mode, theta, wpk, A, grid, st, err);
     if (npass == 2 && mode == MODE_BWD && variant != 3) {
-        if (act == ACT_TANH && variant >= 11 && variant < 18) {   // measurement variants (tools/kbench.py): VAR = variant - 10
-            switch (variant - 10) {
-            case 1: *err = launch_trunkD_t<128, 4, ACT_TANH, 1>(theta, wpk, A, grid, st); return true;
-            case 2: *err = launch_trunkD_t<128, 4, ACT_TANH, 2>(theta, wpk, A, grid, st); return true;
-            case 4: *err = launch_trunkD_t<128, 4, ACT_TANH, 4>(theta, wpk, A, grid, st); return true;
-            default: break;
-            }
+        if (act == ACT_TANH && variant == 11) {   // measurement variant (tools/kbench.py): round 3's lane-linear exchange slots
+            *err = launch_trunkD_t<128, 4, ACT_TANH, 1>(theta, wpk, A, grid, st);
+            return true;
         }
         *err = act == ACT_TANH ? launch_trunkD_t<128, 4, ACT_TANH>(theta, wpk, A, grid, st)
                                : launch_trunkD_t<128, 4, ACT_SIGMOID>(theta, wpk, A, grid, st);

@@ -331,6 +331,57 @@ def test_sampler_is_bit_exact_and_counts_feed_the_kernel():
     assert torch.equal(o1, o2)
 
 
+def test_data_parallel_entries_carry_the_set_sizes_as_floats():
+    """pinn_sample_dp / pinn_adam_dp (round 4): the sampler also writes its two boundary-set sizes as floats (exact below
+    2^24) -- straight into the two spare floats behind [grad | loss terms] in the Trainer -- and the Adam kernel that
+    consumes the all-reduced message stores them back as int64: no conversion kernels in a data-parallel step.  Points,
+    masks and the int64 sizes are those of pinn_sample; the parameter update is that of pinn_adam, bit for bit."""
+    arch, f = make()
+    n = 70001
+    h = capi.Handle(arch, 0, n)
+    pts = [torch.empty(n, device=DEV) for _ in range(4)]
+    pts2 = [torch.empty(n, device=DEV) for _ in range(4)]
+    mask, mask2 = [torch.empty(n, device=DEV, dtype=torch.uint8) for _ in range(2)]
+    counts, counts2 = [torch.zeros(2, device=DEV, dtype=torch.int64) for _ in range(2)]
+    msg = torch.zeros(h.P + 5, device=DEV)
+    h.sample(7, 3, 0, n, 18.0, 0.2, 4.0, 0.005, 17.5, *pts, mask, counts)
+    h.sample(7, 3, 0, n, 18.0, 0.2, 4.0, 0.005, 17.5, *pts2, mask2, counts2, counts_f32=msg[h.P + 3:])
+    h.sample(7, 3, 0, n, 18.0, 0.2, 4.0, 0.005, 17.5, *pts2, mask2, None, counts_f32=msg[h.P + 3:])   # floats only
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(pts, pts2)) and torch.equal(mask, mask2) and torch.equal(counts, counts2)
+    assert msg[h.P + 3:].tolist() == [float(v) for v in counts.tolist()] and float(msg[:h.P + 3].abs().sum()) == 0.0
+    # two ranks' worth of sizes "all-reduced" (doubled), then through the Adam kernel
+    w = np.load(os.path.join(os.path.dirname(__file__), "golden", "g1_weights.npz"))["ionHsym"]
+    g = np.random.default_rng(1).normal(0, 1e-3, h.P + 5).astype(np.float32)
+    st = lambda: dict(theta=dev32(w), m=torch.zeros(h.P, device=DEV), v=torch.zeros(h.P, device=DEV),
+                      step=torch.zeros(1, device=DEV, dtype=torch.int32))
+    a, b = st(), st()
+    grad = torch.tensor(g, device=DEV)
+    grad[h.P + 3:] = 2 * msg[h.P + 3:]
+    out = torch.zeros(2, device=DEV, dtype=torch.int64)
+    h.adam(a["theta"], grad, a["m"], a["v"], a["step"], 8e-3, 0.9, 0.999, 1e-8, (1 << 63) - 1)
+    h.adam(b["theta"], grad, b["m"], b["v"], b["step"], 8e-3, 0.9, 0.999, 1e-8, (1 << 63) - 1,
+           msg_counts=grad[h.P + 3:], counts_out=out)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a[k], b[k]) for k in a) and out.tolist() == [2 * int(v) for v in counts.tolist()]
+
+
+def test_one_shot_exchange_reports_a_sum_that_is_not_finite():
+    """advisor finding, round 3: a rank that timed out pushes the NaN message it was left with on its next call, and its
+    partners must learn of it -- the sum kernel sets the sticky status (code 2) whenever a summed value is not finite,
+    and status() raises.  One rank is enough to see it: the rank's own message carries the NaN."""
+    x = capi.Exchange(0, 0, 1, 1024, lambda mine: [mine])
+    buf = torch.ones(777, device=DEV)
+    x.allreduce(buf)
+    x.status()                                          # finite sum: fine
+    assert float(buf.sum()) == 777.0
+    buf[5] = float("nan")
+    x.allreduce(buf)
+    with pytest.raises(capi.PinnError, match="not finite"):
+        x.status()
+    x.close()
+
+
 def test_sampler_nucleus_clamp_branch_is_bit_exact():
     """train.py:32-35 / poc/main.py:147-149: points closer than `cutoff` to a nucleus get x := cutoff
     (an assignment, not a projection).  With the reference's cutoff (0.005) the branch has probability
@@ -1102,6 +1153,40 @@ def test_flat_train_py_surface(tmp_path):
     tr = pkg.Trainer(m, p, n_points=10000, lr=0.0, device=DEV)
     tr.step()
     assert tr.losses()[0] < 10 * np.median(h["Ltot"][-50:])
+
+
+def test_flat_train_prints_train_pys_five_numbers(capsys):
+    """train.py:61-64 prints Ltot, Lpde, Lbc, (mean(e)) and [Lbest] every tenth pass; mean(e) is the E-net's mean over the
+    batch at the parameters the loss was evaluated at"""
+    import re
+    from pinn_for_quantum_wavefunction_surfaces_amd import flat
+    torch.manual_seed(12345)
+    params = flat.init_params()
+    flat.train(params, lr=8e-3, epochs=11, n=2000, device=DEV, verbose=True)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(lines) == 2                                   # passes 0 and 10
+    m = re.match(r"\s*0: (\S+) (\S+) (\S+) \((\S+)\) \[(\S+)\]$", lines[0])
+    assert m, lines[0]
+    ltot, lpde, lbc, emean, lbest = [float(v) for v in m.groups()]
+    assert abs(ltot - (lpde + lbc)) <= 0.02 * ltot and lbest <= ltot * 1.01 and -3.0 < emean < 1.0      # (printed with three digits)
+
+
+def test_a_trainer_keeps_its_handle_when_the_model_needs_a_larger_one(golden_dir):
+    """advisor finding, round 3: NN_ion._handle_for used to CLOSE the model's handle when a caller needed more points
+    (energy_from_psi on an n_test^3 grid after a Trainer with fewer points), leaving the Trainer with a destroyed
+    handle.  Now the larger workspace is a new handle and the old one lives as long as somebody holds it."""
+    w = np.load(os.path.join(golden_dir, "g1_weights.npz"))
+    params = dict(pkg.set_params(), n_test=24)               # 13 824 grid points > the Trainer's 4 096
+    model = pkg.NN_ion(params).to(DEV)
+    model.load_flat_params(torch.tensor(w["ionHsym"]))
+    tr = pkg.Trainer(model, params, n_points=4096, lr=1e-4, device=DEV)
+    tr.step()
+    l0 = tr.losses()[0]
+    h_before = tr.h
+    E_int, E_net = pkg.energy_from_psi(1.0, params, model)
+    assert np.isfinite(E_int) and model._handles[0] is not h_before and h_before.h is not None
+    tr.step()
+    assert np.isfinite(tr.losses()[0]) and tr.losses()[0] < 100 * l0   # another batch at trained weights: same order
 
 
 def test_energy_from_psi_matches_oracle_quadrature(golden_dir):

@@ -116,12 +116,12 @@ ARCHS["mid32"] = dict(H=32, L=2, HE=16, HG=8, act=0, n_pass=2, out_scale=1.0, pr
 ARCHS["wide4x64x3"] = dict(ARCHS["wide4x64"], precision="bf16x3", dtype="bf16x3",
                            label="4x64 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk (hi+lo "
                                  "operands, 3 MFMAs per product, fp32 accumulate), seeded random init")
-# BASELINE config 1: "100k points/step, 4x128 MLP, fp32": the fp32-grade (split-bf16) 4x128 kernel at
-# 100 000 points per step
+# BASELINE config 1: "100k points/step, 4x128 MLP, fp32": the split-bf16 4x128 kernel (16 operand bits, fp32 accumulation
+# and elementwise; psi, lap, E at <= 1e-5; gradient vs genuine fp32: DESIGN.md section 6) at 100 000 points per step
 ARCHS["wide4x128x3"] = dict(ARCHS["wide4x128"], precision="bf16x3", dtype="bf16x3", points=100000,
-                            label="BASELINE config 1: 4x128 tanh trunk + 2x32 E-net + 1x10 gate, fp32-grade "
-                                  "(split-bf16 MFMA trunk: hi+lo operands, 3 MFMAs per product, fp32 accumulate "
-                                  "and elementwise), 100 000 points/step, seeded random init")
+                            label="BASELINE config 1: 4x128 tanh trunk + 2x32 E-net + 1x10 gate, split-bf16 MFMA trunk "
+                                  "(hi+lo operands = 16 mantissa bits, 3 MFMAs per product, fp32 accumulate and "
+                                  "elementwise; psi/lap/E <= 1e-5), 100 000 points/step, seeded random init")
 # HBM bytes per launch of each workload's trunk kernel: read from profiles/traffic.json, which tools/profile_round.sh
 # (tools/summarize_prof.py) writes from the rocprofv3 PMC passes of the same bench command -- FETCH_SIZE x 2 (the gfx950
 # correction for wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE, mean per launch, keyed by kernel.  No file, or
@@ -166,7 +166,9 @@ SECONDARY = {"wide64": ["wide64x3", "wide4x128x3", "ref16", "ref16ft", "wide128"
 PARITY_BAR = {
     "f32": "psi, E, lap 1e-5 rel; residual 2e-5; loss 1e-4; gradient 1e-4",
     "bf16": "psi 1e-2, lap 1e-2, residual 2e-2, loss 3e-2, gradient 3e-2 rel (bf16 operands cannot meet 1e-5)",
-    "bf16x3": "psi, lap 1e-5 rel; residual 5e-5; loss, gradient 2e-4 (split-bf16 operands, fp32 accumulate)",
+    "bf16x3": "psi, lap 1e-5 rel; residual 5e-5; loss, gradient 2e-4 on sampled batches (split-bf16: 16 operand bits, fp32 "
+              "accumulate; on a batch dominated by points 0.01-0.2 a.u. from a nucleus the gradient is within 16x of what "
+              "the reference gives in fp32 torch, observed 9.5x: tests/test_gpu_parity.py, DESIGN.md section 6)",
 }
 REF_ARCH = dict(H=16, L=2, HE=32, HG=10, act=0, n_pass=2, out_scale=1.0)
 HAM_A = dict(a=-0.5, b=-1.0, c=-1.0, P=1.0)

@@ -221,3 +221,35 @@ def test_simpson_weight_vector_is_scipys_rule(n):
         f3 = rng.normal(size=(n, n, n))
         nested = simpson([simpson([simpson(fx, x=x) for fx in fy], x=x) for fy in f3], x=x)
         assert abs(np.einsum("i,j,k,ijk->", w, w, w, f3) - nested) < 1e-10 * np.abs(f3).sum()
+
+
+def test_profile_summary_keys_and_the_traffic_file_bench_reads():
+    """tools/summarize_prof.py names a trunk kernel the same whether rocprofv3 printed it demangled or mangled, and
+    bench.py takes `roofline.traffic` of every workload from the committed profiles/traffic.json (round 4; round 3 had the
+    numbers pasted into bench.py)"""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "tools", "summarize_prof.py")).read()
+    ns = {}
+    exec(src[:src.index("root = sys.argv[1]")], ns)
+    key = ns["kernel_key"]
+    assert key("void (anonymous namespace)::k_trunkD<128, 4, 1, 0>(float const*, bool") == "trunkD_128"
+    assert key("_ZN12_GLOBAL__N_18k_trunk2ILi64ELi1ELb1EEEvPKfPKDF16b9TrunkArgs") == "trunk2_64"
+    assert key("space)::k_trunk16<0, 2, 1>(float const*, TrunkArgs)") == "trunk16_bwd"
+    assert key("space)::k_trunk16<0, 2, 2>(float const*, TrunkArgs)") == "trunk16_head"
+    assert key("k_trunk2sILi64ELi1EEEvPKfPKDF16b9TrunkArgs") == "trunk2s_64" and key("k_trunkDx<1>(float") == "trunkDx"
+    assert key("k_sample(unsigned long") is None
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys_mod = list(__import__("sys").argv), __import__("sys")
+    sys_mod.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys_mod.argv = argv
+    for arch, k in bench.TRAFFIC_KERNEL_KEY.items():
+        assert arch in bench.ARCHS and k in t["bytes_per_launch"], (arch, k)
+        assert bench.TRAFFIC[arch] == t["bytes_per_launch"][k] > 1e6
+    assert "FETCH_SIZE" in bench.TRAFFIC_SOURCE

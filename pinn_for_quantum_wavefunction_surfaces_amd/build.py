@@ -12,15 +12,22 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libpinn_hip.so")
 # translation units: (object name, source, extra flags).  pinn_kernels.hip: -fno-slp-vectorize, because the SLP
 # pass packs scalar FMAs into v_pk_* and then has to copy the SGPR-resident weights into VGPR pairs first (+40 %
-# VALU instructions).  pinn_trunk_mfma.hip is compiled twice: part 0 (everything but the 4x128 kernels) keeps SLP
-# (2-4 % faster 2-layer kernels), part 1 (the 4x128 kernels) drops it (fewer spills at that register pressure:
-# 4-19 % faster).
+# VALU instructions).  The matrix-core trunk kernels are one translation unit per kernel family (they compile in
+# parallel); pinn_trunk_general.hip and pinn_trunk_deep.hip are compiled twice: part 0 (everything but the 4x128
+# kernels) keeps SLP (2-4 % faster narrow kernels), part 1 (the 4x128 kernels) drops it (fewer spills at that
+# register pressure: 4-19 % faster).
+NO_SLP_128X4 = ["-DPINN_TRUNK_PART=1", "-fno-slp-vectorize"]
 UNITS = [("pinn_kernels.o", "pinn_kernels.hip", ["-fno-slp-vectorize"]),
          ("pinn_trunk_mfma.o", "pinn_trunk_mfma.hip", []),
-         ("pinn_trunk_mfma_p1.o", "pinn_trunk_mfma.hip", ["-DPINN_TRUNK_PART=1", "-fno-slp-vectorize"]),
+         ("pinn_trunk_merged.o", "pinn_trunk_merged.hip", []),
+         ("pinn_trunk_deep.o", "pinn_trunk_deep.hip", []),
+         ("pinn_trunk_deep_p1.o", "pinn_trunk_deep.hip", NO_SLP_128X4),
+         ("pinn_trunk_general.o", "pinn_trunk_general.hip", []),
+         ("pinn_trunk_general_p1.o", "pinn_trunk_general.hip", NO_SLP_128X4),
+         ("pinn_rnet_mfma.o", "pinn_rnet_mfma.hip", []),
          ("pinn_xchg.o", "pinn_xchg.hip", [])]
 SOURCES = sorted({u[1] for u in UNITS})
-HEADERS = ["pinn_math.h", "pinn_common.h", os.path.join("..", "..", "include", "pinn.h")]
+HEADERS = ["pinn_math.h", "pinn_common.h", "pinn_mfma_common.h", os.path.join("..", "..", "include", "pinn.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

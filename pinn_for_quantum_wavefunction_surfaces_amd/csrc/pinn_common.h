@@ -22,30 +22,41 @@ struct TrunkArgs {
     int stride;
 };
 
-// ---- MFMA trunk (pinn_trunk_mfma.hip): bf16 operands, fp32 accumulate --------------------
-// packed bf16 weights for one call: [(L-1)][2 (fwd, bwd)][H*H] (see pack order there)
-size_t mfma_packed_weight_bytes(int H, int L);
+// ---- MFMA trunk: bf16 operands, fp32 accumulate (dispatch in pinn_trunk_mfma.hip, kernels in pinn_trunk_merged.hip,
+// pinn_trunk_deep.hip, pinn_trunk_general.hip; conventions in pinn_mfma_common.h)
 bool mfma_trunk_supported(int H, int L);
-int mfma_partial_stride(int H, int L);
+bool mfma_x3_supported(int H, int L);            // split-bf16 (fp32-grade) operands
+// packed bf16 weights for one call: [(L-1)][2 (fwd, bwd)][H*H], hi and lo planes (pack order: k_pack_weights)
+size_t mfma_packed_weight_bytes(int H, int L);
+int mfma_partial_stride(int H, int L);           // floats per block partial row (trunk grads + 3)
 size_t mfma_stash_bytes(int H, int L, bool x3, int nblocks);   // k_trunkD's parked state, behind the packed weights
-int mfma_blocks_per_cu(int H, int L, bool x3);   // resident blocks per CU of the chosen kernel   // floats per block partial row (trunk grads + 3)
+int mfma_blocks_per_cu(int H, int L, bool x3);   // resident blocks per CU of the chosen kernel
 // enqueue pack + trunk kernel; returns false when (H, L, act, npass, mode) has no instantiation
-bool mfma_x3_supported(int H, int L);
-// the 4x128 shapes live in a second translation unit of pinn_trunk_mfma.hip (built without SLP vectorization)
-bool launch_trunk_mfma_128x4(int act, int npass, int mode, bool x3, int variant, const float* theta, void* packed_weights,
-                             const TrunkArgs& A, int grid, hipStream_t st, hipError_t* err);
 bool launch_trunk_mfma(int H, int L, int act, int npass, int mode, bool x3, const float* theta,
                        void* packed_weights, const TrunkArgs& A, int grid, hipStream_t st,
                        hipError_t* err);
+// the per-family entry points launch_trunk_mfma chooses from (same contract; `variant` = PINN_MFMA_VARIANT).  The
+// 4x128 kernels live in second translation units of their files, built without SLP vectorization (build.py)
+bool launch_trunk_merged(int H, int act, int npass, int mode, bool x3, int variant, const float* theta,
+                         void* packed_weights, const TrunkArgs& A, int grid, hipStream_t st, hipError_t* err);
+bool launch_trunk_deep(int H, int act, int npass, int mode, bool x3, int variant, const float* theta,
+                       void* packed_weights, const TrunkArgs& A, int grid, hipStream_t st, hipError_t* err);
+bool launch_trunk_deep_128(int act, bool x3, int variant, const float* theta, void* packed_weights,
+                           const TrunkArgs& A, int grid, hipStream_t st, hipError_t* err);
+size_t trunk_deep_stash_block_bytes(int H, bool x3);
+bool launch_trunk_general(int H, int L, int act, int npass, int mode, bool x3, const float* theta, void* packed_weights,
+                          const TrunkArgs& A, int grid, hipStream_t st, hipError_t* err);
+bool launch_trunk_general_128x4(int act, int npass, int mode, bool x3, const float* theta, void* packed_weights,
+                                const TrunkArgs& A, int grid, hipStream_t st, hipError_t* err);
 
-// ---- R-only nets on the matrix pipe (pinn_trunk_mfma.hip): (HE, HG) = (32, 10), split-bf16 operands
+// ---- R-only nets on the matrix pipe (pinn_rnet_mfma.hip): (HE, HG) = (32, 10), split-bf16 operands
 bool rnet_mfma_supported(int HE, int HG);
 hipError_t launch_rnet_mfma_fwd(int act, const float* thE, const float* R, int64_t n, float* E, float* g,
                                 float* Eu, int grid, hipStream_t st);
 hipError_t launch_rnet_mfma_bwd(int act, const float* thE, const float* R, const float* Eb, const float* gb,
                                 int64_t n, float* part, int stride, int grid, hipStream_t st);
 
-// ---- the 16-wide reference trunk on the matrix pipe (pinn_trunk_mfma.hip, k_trunk16): two blocks per CU,
+// ---- the 16-wide reference trunk on the matrix pipe (pinn_rnet_mfma.hip, k_trunk16): two blocks per CU,
 // 64 points per block and trip
 bool trunk16_mfma_supported(int H, int L);
 hipError_t launch_trunk16_mfma(int act, int npass, int mode, const float* theta, const TrunkArgs& A, int grid,

@@ -944,7 +944,7 @@ def test_deep_split_bf16_kernel_ragged_sizes_and_ring_refill(n):
 def test_bitwise_reproducible_with_co_resident_blocks(H, L, prec):
     """131 072 points = a full persistent grid (two workgroups per CU where the kernel is built for that): four
     calls with the same inputs return the same bits.  Round 2 found k_trunk2<64> differing from run to run in
-    exactly this regime (packed fp32 op_sel forms on the point-record ring, see lin2 in csrc/pinn_trunk_mfma.hip);
+    exactly this regime (packed fp32 op_sel forms on the point-record ring, see lin2 in csrc/pinn_mfma_common.h);
     small batches, which place one workgroup per CU, never showed it."""
     n = 131072
     form_b = prec.endswith("-B")            # train.py's formulation: one pass, two tiles per trip in k_trunk2

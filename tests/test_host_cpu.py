@@ -180,10 +180,11 @@ def test_torch_baseline_matches_oracle(golden_dir):
 def test_no_packed_opsel_forms_in_any_trunk_kernel():
     """hipcc's v_pk_{mul,fma,add}_f32 ... op_sel:[..] (the LOW result lane reading the HIGH dword of an operand
     pair) intermittently computed with 0 in place of that dword on MI355X (profiles/r02_packed_opsel.md,
-    tools/opselbench; cause open: compiler or hardware, profiles/r03_packed_opsel.md).  The sources of
-    csrc/pinn_trunk_mfma.hip are written so that none is emitted (lin2, fmac_bcast, ring_splats), and since round 4
-    so are the exact-fp32 vector kernels of csrc/pinn_kernels.hip (bcast_elem in pinn_math.h); this compiles all three
-    translation units to assembly (no GPU needed) and looks."""
+    tools/opselbench; cause open: compiler or hardware, profiles/r03_packed_opsel.md).  The matrix-core trunk
+    kernels (csrc/pinn_trunk_*.hip, csrc/pinn_rnet_mfma.hip) are written so that none is emitted (lin2, fmac_bcast,
+    ring_splats in csrc/pinn_mfma_common.h), and since round 4 so are the exact-fp32 vector kernels of
+    csrc/pinn_kernels.hip (bcast_elem in pinn_math.h); this compiles every arithmetic translation unit to assembly
+    (no GPU needed) and looks."""
     import shutil
     import sys
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):

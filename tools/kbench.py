@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """kbench -- A/B timing of trunk-kernel variants in ONE process, interleaved rounds (HIP events inside the
 library, pinn_profile_*): `python tools/kbench.py --arch wide64 --variants 0,1,2 [--points 1000000]`.
-A variant is an alternative instantiation selected by PINN_MFMA_VARIANT (csrc/pinn_trunk_mfma.hip).
+A variant is an alternative instantiation selected by PINN_MFMA_VARIANT (csrc/pinn_trunk_mfma.hip picks the kernel).
 Caveat (round 4): with the variants alternating every `--steps` steps the chip's clock control sees a mix, and a variant that
 stalls less is flattered (k_trunk2's swizzle: -4.4 % here, -2.4 % as separate steady processes).  Quote gains from
 tools/ab_steady.sh; use this tool to rank variants and to check that they agree bit for bit (theta checksum)."""

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """List packed-fp32 VALU instructions whose LOW result lane reads the HIGH dword of an operand pair
-(v_pk_{mul,fma,add}_f32 ... op_sel:[..1..]) per kernel of csrc/pinn_trunk_mfma.hip and csrc/pinn_kernels.hip.
+(v_pk_{mul,fma,add}_f32 ... op_sel:[..1..]) per kernel of the library's translation units (the matrix-core trunk files csrc/pinn_trunk_*.hip,
+csrc/pinn_rnet_mfma.hip, and csrc/pinn_kernels.hip).
 
     python tools/opsel_check.py [substring ...]
 
@@ -45,7 +46,7 @@ def compile_and_scan():
     with tempfile.TemporaryDirectory() as d:
         procs = []
         for objname, src, extra in UNITS:
-            if src not in ("pinn_trunk_mfma.hip", "pinn_kernels.hip"):
+            if src in ("pinn_xchg.hip", "pinn_trunk_mfma.hip"):      # no arithmetic kernels (exchange; dispatch only)
                 continue
             out = os.path.join(d, objname + ".s")
             procs.append((out, subprocess.Popen(

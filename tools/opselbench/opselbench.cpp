@@ -1,6 +1,6 @@
 // opselbench -- does v_pk_mul_f32 / v_pk_fma_f32 with op_sel:[0,1] (the LOW result lane reading the HIGH dword
 // of an operand pair) always deliver the product of its operands on MI355X?  Background: k_trunk2 (csrc/
-// pinn_trunk_mfma.hip) gave run-to-run different d/dx-stream values with two workgroups per CU until its
+// pinn_trunk_merged.hip) gave run-to-run different d/dx-stream values with two workgroups per CU until its
 // ring-fed broadcast arithmetic was moved to unpacked VALU instructions (profiles/r02_packed_opsel.md).
 // This program tries to isolate that: every lane reads a 16-byte record from LDS (ds_read_b128, as the kernel
 // does), multiplies a per-lane weight pair by the record's SECOND dword with the packed op_sel form and with

@@ -170,12 +170,16 @@ __global__ __launch_bounds__(kBlock) void k_rnet_mfma_fwd(const float* __restric
     bf16x8 Ah[2], Am[2], Al[2];
 #pragma unroll
     for (int jt = 0; jt < 2; jt++) rnet_weight_frag3(thE + Lo.WE2(), jt, g, c, Ah[jt], Am[jt], Al[jt]);
-    const int64_t ntile = (n + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntile;
-         tile += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int64_t ntile = (n + 15) / 16, tstep = (int64_t)gridDim.x * kWavesPerBlock;
+    // the next trip's R is requested before this trip's arithmetic: one exposed load per wave, not one per tile
+    auto clampi = [n](int64_t i) { return i < n ? i : n - 1; };
+    int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    float Rnext = tile < ntile ? R[clampi(tile * 16 + c)] : 0.f;
+    for (; tile < ntile; tile += tstep) {
         const int64_t idx = tile * 16 + c;
         const bool valid = idx < n;
-        const float Rv = R[valid ? idx : n - 1];
+        const float Rv = Rnext;
+        if (tile + tstep < ntile) Rnext = R[clampi((tile + tstep) * 16 + c)];
         float e, gg;
         rnet_tile_forward_fine<ACT>(K, Ah, Am, Al, Rv, e, gg);
         if (valid && g == 0) {
@@ -220,14 +224,22 @@ __global__ __launch_bounds__(kBlock, 2) void k_rnet_mfma_bwd(const float* __rest
         wacc[a][0] = splat(0.f); wacc[a][1] = splat(0.f);
     }
     const float lead = g == 0 ? 1.0f : 0.0f;
-    const int64_t ntile = (n + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntile;
-         tile += (int64_t)gridDim.x * kWavesPerBlock) {
-        const int64_t idx = tile * 16 + c;
-        const bool valid = idx < n;
-        const int64_t id = valid ? idx : n - 1;
-        const float Rv = R[id];
-        const float ebv = valid ? Eb[id] : 0.f, gbv = valid ? gb[id] : 0.f;
+    const int64_t ntile = (n + 15) / 16, tstep = (int64_t)gridDim.x * kWavesPerBlock;
+    // the next trip's point record (R, E-bar, g-bar) is requested before this trip's arithmetic
+    int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    float Rn = 0.f, ebn = 0.f, gbn = 0.f;
+    auto request = [&](int64_t t) {
+        const int64_t i = t * 16 + c;
+        const bool ok = i < n;
+        const int64_t id = ok ? i : n - 1;
+        Rn = R[id];
+        ebn = ok ? Eb[id] : 0.f;
+        gbn = ok ? gb[id] : 0.f;
+    };
+    if (tile < ntile) request(tile);
+    for (; tile < ntile; tile += tstep) {
+        const float Rv = Rn, ebv = ebn, gbv = gbn;
+        if (tile + tstep < ntile) request(tile + tstep);
         f32x4 h1[2], h2[2], hg;
         u32x4 Xbh, Xbl;
         float e, gg;

@@ -109,20 +109,22 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     // 32-bit lane offset, the matrix offset as the scalar offset) -- no per-lane 64-bit addresses for hipcc to
     // hoist out of the tile loop and spill
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wpk_g), 0, NW * 2 * H * H * 2, 0x00020000);
-    const int wvoff = part * KC * 1024 + lane16;
+    // (the wave's part of every buffer offset is uniform and rides in the scalar offset: the only per-lane offset
+    // register of the weight and stash accesses is lane16)
+    const int wsoff = part * KC * 1024;
     auto loadA = [&](int m, bf16x8 (&a)[KC]) {
 #pragma unroll
         for (int kc = 0; kc < KC; kc++)
-            a[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + kc * 1024, m * H * H * 2, 0));
+            a[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + kc * 1024, wsoff + m * H * H * 2, 0));
     };
     // parked saved state of layer l (1..L-2): 8 x u32x2 = 4 x 16 bytes per lane, [k][lane] per wave
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(stash_g, 0, STASH ? (int)(C::STASH_BLOCK * gridDim.x) : 0, 0x00020000);
-    const int svoff = ((blockIdx.x * (NW - 1) * C::WAVES + part) * 256 + lane) * 16;
+    const int ssoff = (blockIdx.x * (NW - 1) * C::WAVES + part) * 4096;
     auto stash_put = [&](int l, int k, u32x4 v) {
-        __builtin_amdgcn_raw_buffer_store_b128(v, srs, svoff + k * 1024, (l - 1) * C::WAVES * 4096, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, srs, lane16 + k * 1024, ssoff + (l - 1) * C::WAVES * 4096, 0);
     };
     auto stash_get = [&](int l, int k) {
-        return __builtin_amdgcn_raw_buffer_load_b128(srs, svoff + k * 1024, (l - 1) * C::WAVES * 4096, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(srs, lane16 + k * 1024, ssoff + (l - 1) * C::WAVES * 4096, 0);
     };
 
     f32x4 wacc[NW][HT], bacc[L], w0acc0 = splat(0.f), w0acc1 = splat(0.f), woacc = splat(0.f);
@@ -587,11 +589,14 @@ struct TDxCfg {
     static_assert(OFF_S % 16 == 0 && OFF_R % 16 == 0, "alignment");
 };
 
-template <int ACT>
+// VAR (measurement variants, tools/kbench.py): bit 0 = swizzled exchange slots (as in k_trunkD) instead of lane-linear;
+// bit 1 = operand fragments requested per k chunk right before its MFMAs (rounds 3-4) instead of pipelined in place
+template <int ACT, int VAR = 0>
 __global__ __launch_bounds__(TDxCfg::WAVES * 64, 2)
 void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, uint4* __restrict__ stash_g, TrunkArgs A)
 {
     using C = TDxCfg;
+    constexpr bool SWZ = (VAR & 1) != 0, PIPE = (VAR & 2) == 0;
     constexpr int H = C::H, L = C::L, HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB, EB1 = C::EB1, NW = C::NW;
     using Lay = TrunkLayout<H, L>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -609,11 +614,18 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     const int lane = threadIdx.x & 63;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int lane16 = lane * 16;
-    // (lane-linear exchange slots: the swizzle of the other merged-pass kernels costs this one a register it does not
-    // have -- 0.906 -> 0.946 ms per 100 000 points with it, A/B on one box, round 4)
-    const int own_slot = lane16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
-    const int trl = (g >> 1) * 1024 + (8 * (g & 1) + (c >> 2)) * 16 + (c & 1) * 8 + ((c & 3) >> 1) * 256;
+    // Exchange slots: lane-linear.  SWZ (measurement variant) permutes them as in k_trunkD (odd lane groups by c ^ 12:
+    // conflict-free transposed reads): the second transposed read of a fragment, at slot c' + 4, then sits 64 bytes
+    // ABOVE the first for even source groups and 64 bytes BELOW for odd ones -- in both cases the first address with
+    // bit 6 flipped, so it is formed by one v_xor per weight-gradient phase instead of living in a register, and the
+    // lane-linear offset of the weight loads is rebuilt from the slot offset where it is used.  Measured (round 4,
+    // steady A/B on one box): bank conflicts -64 %, LDS-array cycles -18 %, kernel +1.5 % (0.850 -> 0.866 ms per
+    // 100 000 points; with a resident second address +4.4 %): the array is busy half the kernel's time either way, what
+    // the waves wait for is its latency under eight waves' simultaneous requests.  Not the default.
+    auto slot16 = [](int gg, int cc) { return (gg * 16 + (SWZ ? (cc ^ ((gg & 1) * 12)) : cc)) * 16; };
+    const int sw16 = SWZ ? slot16(g, c) : lane * 16;
+    const int own_slot = sw16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
+    const int trl = (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2)) + (c & 1) * 8;
     const int n0 = 16 * part + 4 * g;
 
     for (int k = threadIdx.x; k < H; k += NT) {
@@ -631,14 +643,14 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     // A fragments of matrix m = (l - 1) * 2 + dir of this wave's 16 rows: hi plane, lo plane (one packed plane later)
     constexpr int WPLANE_B = NW * 2 * H * H * 2;                  // bytes of one packed weight plane
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wpk_g), 0, 2 * WPLANE_B, 0x00020000);
-    const int wvoff = part * KC * 1024 + lane16;
+    const int wsoff = part * KC * 1024;         // the wave's part of the buffer offsets is uniform: scalar offset
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(stash_g, 0, (int)(C::STASH_BLOCK * gridDim.x), 0x00020000);
-    const int svoff = ((blockIdx.x * (NW - 1) * C::WAVES + part) * 256 + lane) * 16;
+    const int ssoff = (blockIdx.x * (NW - 1) * C::WAVES + part) * 4096;
     auto stash_put = [&](int l, int k, f32x4 v) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, svoff + k * 1024, (l - 1) * C::WAVES * 4096, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, sw16 + k * 1024, ssoff + (l - 1) * C::WAVES * 4096, 0);
     };
     auto stash_get = [&](int l, int k) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, svoff + k * 1024, (l - 1) * C::WAVES * 4096, 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, sw16 + k * 1024, ssoff + (l - 1) * C::WAVES * 4096, 0));
     };
 
     f32x4 wacc[NW][HT], bacc[L], w0acc0 = splat(0.f), w0acc1 = splat(0.f), woacc = splat(0.f);
@@ -688,57 +700,122 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
         *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(eb + EB1 + own_slot + s * 1024) = pl;
     };
     auto bfrag = [&](lds_p eb, int kc, int s) {
-        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + lane16 + (kc * NST + s) * 1024);
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + sw16 + (kc * NST + s) * 1024);
     };
-    auto trfrag = [&](lds_p eb, int T, int ph) {
-        const lds_p p0 = eb + trl + ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p0 + 64));
+    auto trfrag = [&](lds_p eb, int trh, int T, int ph) {
+        const int o = ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trl + o));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trh + o + (SWZ ? 0 : 64)));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
-    // D[own 16 rows][NST column tiles] += A x B, split operands (hi*hi, hi*lo, lo*hi into the same accumulator).  The B
-    // fragments of a k chunk are requested right before its twelve MFMAs (prefetching the next chunk's, 16 more
-    // registers, spilled and was 11 % slower; the SIMD's other wave covers the LDS latency); the A fragments (hi and
-    // lo) of matrix m are streamed from L2 two k chunks ahead: 16 registers in flight instead of 32 resident, -6 %
+    // D[own 16 rows][NST column tiles] += A x B, split operands (hi*hi, lo*hi, hi*lo into the same accumulator).  Operand
+    // fragments are software-pipelined IN PLACE (no second register set -- prefetching into one spilled and was 11 %
+    // slower): the hi-plane fragments of the next k chunk are requested right after the eight MFMAs that read this
+    // chunk's (hi*hi, lo*hi), the lo-plane ones after the four that read those (hi*lo), so each request has four to eight
+    // MFMAs of this wave (and the partner wave's) to land behind instead of stalling the chunk's first MFMA.  The A
+    // fragments (hi and lo) of matrix m are streamed from L2 two k chunks ahead: 16 registers in flight instead of 32
+    // resident, -6 %.  VAR bit 1 = round 3's schedule (all eight fragments of a chunk requested right before its MFMAs).
     auto loadA1 = [&](int m, int kc, bf16x8& ah, bf16x8& al) {
-        ah = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + kc * 1024, m * H * H * 2, 0));
-        al = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + kc * 1024, WPLANE_B + m * H * H * 2, 0));
+        // the packed weights are in lane-linear fragment order; with swizzled slots the lane-linear offset is rebuilt from
+        // sw16 on the spot (three VALU instructions per pair of loads) instead of occupying a register for the whole kernel
+        int lane16 = sw16;
+        if constexpr (SWZ)
+            asm volatile("v_bfe_u32 %0, %1, 8, 1\n\tv_mul_u32_u24 %0, 0xc0, %0\n\tv_xor_b32 %0, %0, %1" : "=&v"(lane16) : "v"(sw16));
+        ah = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + kc * 1024, wsoff + m * H * H * 2, 0));
+        al = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + kc * 1024, wsoff + WPLANE_B + m * H * H * 2, 0));
     };
     auto gemmXs = [&](int m, bf16x8 (&ah)[2], bf16x8 (&al)[2], lds_p eb, f32x4 (&d)[NST]) {
         // ah[0..1], al[0..1] hold chunks 0 and 1 on entry (requested by the caller a phase ahead)
         bf16x8 xh[NST], xl[NST];
+        if constexpr (PIPE) {
 #pragma unroll
-        for (int kc = 0; kc < KC; kc++) {
+            for (int s = 0; s < NST; s++) xh[s] = bfrag(eb, 0, s);
 #pragma unroll
-            for (int s = 0; s < NST; s++) xh[s] = bfrag(eb, kc, s);
+            for (int s = 0; s < NST; s++) xl[s] = bfrag(eb + EB1, 0, s);
 #pragma unroll
-            for (int s = 0; s < NST; s++) xl[s] = bfrag(eb + EB1, kc, s);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int kc = 0; kc < KC; kc++) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc & 1], xh[s], d[s]);
+                for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc & 1], xh[s], d[s]);
 #pragma unroll
-            for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc & 1], xl[s], d[s]);
+                for (int s = 0; s < NST; s++) d[s] = mfma(al[kc & 1], xh[s], d[s]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kc + 1 < KC) {
 #pragma unroll
-            for (int s = 0; s < NST; s++) d[s] = mfma(al[kc & 1], xh[s], d[s]);
-            if (kc + 2 < KC) loadA1(m, kc + 2, ah[kc & 1], al[kc & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int s = 0; s < NST; s++) xh[s] = bfrag(eb, kc + 1, s);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc & 1], xl[s], d[s]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kc + 1 < KC) {
+#pragma unroll
+                    for (int s = 0; s < NST; s++) xl[s] = bfrag(eb + EB1, kc + 1, s);
+                }
+                if (kc + 2 < KC) loadA1(m, kc + 2, ah[kc & 1], al[kc & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) {
+#pragma unroll
+                for (int s = 0; s < NST; s++) xh[s] = bfrag(eb, kc, s);
+#pragma unroll
+                for (int s = 0; s < NST; s++) xl[s] = bfrag(eb + EB1, kc, s);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc & 1], xh[s], d[s]);
+#pragma unroll
+                for (int s = 0; s < NST; s++) d[s] = mfma(ah[kc & 1], xl[s], d[s]);
+#pragma unroll
+                for (int s = 0; s < NST; s++) d[s] = mfma(al[kc & 1], xh[s], d[s]);
+                if (kc + 2 < KC) loadA1(m, kc + 2, ah[kc & 1], al[kc & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
-    // weight gradient of one layer from one pass: K = 64 columns = 2 steps (stream pairs) x HT column tiles
+    // weight gradient of one layer from one pass: K = 64 columns = 2 steps (stream pairs) x HT column tiles, three MFMAs
+    // per (step, tile).  Pipelined in place like the GEMMs: two fragment pairs (hi, lo) in flight, the pair of step
+    // s + 2 requested into the registers of step s right after its three MFMAs.
     auto wgradX = [&](f32x4 (&wa)[HT], lds_p yb, lds_p xb) {
+        int trh = trl;
+        if constexpr (SWZ) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(trh) : "v"(trl));   // not hoisted: see above
+        if constexpr (PIPE) {
+            bf16x8 fyh = trfrag(yb, trh, part, 0), fyl = trfrag(yb + EB1, trh, part, 0);
+            bf16x8 xs[2][2];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const bf16x8 fyh = trfrag(yb, part, k), fyl = trfrag(yb + EB1, part, k);
+            for (int q = 0; q < 2; q++) { xs[q][0] = trfrag(xb, trh, q, 0); xs[q][1] = trfrag(xb + EB1, trh, q, 0); }
 #pragma unroll
-            for (int i0 = 0; i0 < HT; i0 += 2) {
-                bf16x8 fxh[2], fxl[2];
+            for (int st = 0; st < 2 * HT; st++) {
+                const int T = st & (HT - 1), q = st & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (st == HT) { fyh = trfrag(yb, trh, part, 1); fyl = trfrag(yb + EB1, trh, part, 1); }
+                wa[T] = mfma(fyh, xs[q][0], wa[T]);
+                wa[T] = mfma(fyl, xs[q][0], wa[T]);
+                wa[T] = mfma(fyh, xs[q][1], wa[T]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 2 < 2 * HT) {
+                    const int T2 = (st + 2) & (HT - 1), k2 = (st + 2) / HT;
+                    xs[q][0] = trfrag(xb, trh, T2, k2);
+                    xs[q][1] = trfrag(xb + EB1, trh, T2, k2);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
-                for (int i = 0; i < 2; i++) { fxh[i] = trfrag(xb, i0 + i, k); fxl[i] = trfrag(xb + EB1, i0 + i, k); }
+            for (int k = 0; k < 2; k++) {
+                const bf16x8 fyh = trfrag(yb, trh, part, k), fyl = trfrag(yb + EB1, trh, part, k);
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    wa[i0 + i] = mfma(fyh, fxh[i], wa[i0 + i]);
-                    wa[i0 + i] = mfma(fyh, fxl[i], wa[i0 + i]);
-                    wa[i0 + i] = mfma(fyl, fxh[i], wa[i0 + i]);
+                for (int i0 = 0; i0 < HT; i0 += 2) {
+                    bf16x8 fxh[2], fxl[2];
+#pragma unroll
+                    for (int i = 0; i < 2; i++) { fxh[i] = trfrag(xb, trh, i0 + i, k); fxl[i] = trfrag(xb + EB1, trh, i0 + i, k); }
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        wa[i0 + i] = mfma(fyh, fxh[i], wa[i0 + i]);
+                        wa[i0 + i] = mfma(fyh, fxl[i], wa[i0 + i]);
+                        wa[i0 + i] = mfma(fyl, fxh[i], wa[i0 + i]);
+                    }
                 }
             }
         }
@@ -761,6 +838,15 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     PointRec nxt = load_rec(0);
     bf16x8 afh[2], afl[2];
     auto loadA2 = [&](int m) { loadA1(m, 0, afh[0], afl[0]); loadA1(m, 1, afh[1], afl[1]); };
+    // -DPINN_STAMPS (diagnostic build, tools/stamps.py): per-wave cycle totals by kind of phase, summed over the three stages
+#ifdef PINN_STAMPS
+    unsigned long long st_acc[24], st_last = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int i = 0; i < 24; i++) st_acc[i] = 0;
+#define TDX_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define TDX_STAMP(i) do { } while (0)
+#endif
     for (int64_t itx = 0; itx < iters; itx++) {
         const int64_t tile = itx * gridDim.x + blockIdx.x;
         const int64_t idx = tile * 16 + c;
@@ -772,6 +858,7 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
             nxt = load_rec(itx / RB + 1);
             __syncthreads();
         }
+        TDX_STAMP(23);
         float tNb = 0.f, tlapNb = 0.f;      // adjoints of N and lap N (from the tail), shared by both reverse passes
 #pragma unroll 1
         for (int stage = 0; stage < 3; stage++) {
@@ -796,7 +883,9 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 put(X0, 2, s1 * a[2]);
                 put(X0, SLP, s1 * a[SLP] + s2 * q);
             }
+            TDX_STAMP(0);
             __syncthreads();
+            TDX_STAMP(1);
             f32x4 st3[NST];                 // (h, a_x, a_rho, a_lap) of the last hidden layer of this pass
 #pragma unroll
             for (int l = 1; l < L; l++) {
@@ -809,6 +898,7 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 gemmXs((l - 1) * 2, afh, afl, Xin, acc);
                 if (l < L - 1) loadA2(l * 2);                             // next layer's forward matrix (first two chunks)
                 __builtin_amdgcn_sched_barrier(0);
+                TDX_STAMP(1 + l);
                 f32x4 s0, s1, s2;
                 act012v<ACT>(acc[0], s0, s1, s2);
                 const f32x4 q = acc[1] * acc[1] + acc[2] * acc[2];
@@ -831,7 +921,9 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                     const float tot = xg_sum_pair(dot4(wo, s0), dot4(wo, ol));
                     if ((g & 1) == 0) SB[((part * 16 + c) * 2 + ps) * 2 + (g >> 1)] = tot;
                 }
+                TDX_STAMP(4 + l);
                 __syncthreads();
+                TDX_STAMP(8);
             }
             if (stage == 0) continue;
             // ================= tail (once, when both passes' output sums are there) =================
@@ -877,7 +969,9 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 put(YB, 2, u * st3[2]);
                 put(YB, SLP, s1 * ol);
             }
+            TDX_STAMP(9);
             __syncthreads();
+            TDX_STAMP(10);
             // ================= reverse steps l = L-1 .. 1 of pass ps =================
 #pragma unroll
             for (int l = L - 1; l >= 1; l--) {
@@ -891,10 +985,12 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 // earlier: 32 registers less through the elementwise phase, where the pressure peaks)
                 loadA2((l - 1) * 2 + 1);
                 wgradX(wacc[l - 1], YB, Xin);
+                TDX_STAMP(14 - l);
                 f32x4 ob[NST];
 #pragma unroll
                 for (int s = 0; s < NST; s++) ob[s] = splat(0.f);
                 gemmXs((l - 1) * 2 + 1, afh, afl, YB, ob);
+                TDX_STAMP(17 - l);
                 if (l > 1) {
                     const f32x4 h = sq[0], a1 = sq[1], a2 = sq[2], al_ = sq[3];
                     f32x4 s1, s2, s3;
@@ -904,12 +1000,16 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                     const f32x4 y0 = s1 * ob[0] + s2 * (a1 * ob[1] + a2 * ob[2]) + (s2 * al_ + s3 * q) * ob[SLP];
                     const f32x4 y1 = s1 * ob[1] + u * a1, y2 = s1 * ob[2] + u * a2, y3 = s1 * ob[SLP];
                     bacc[l - 1] += y0;
+                    TDX_STAMP(20 - l);
                     __syncthreads();                // every wave has read YB (and X[l-1])
+                    TDX_STAMP(20);
                     put(YB, 0, y0);
                     put(YB, 1, y1);
                     put(YB, 2, y2);
                     put(YB, SLP, y3);
+                    TDX_STAMP(21);
                     __syncthreads();
+                    TDX_STAMP(22);
                 } else {
                     float f[2][NST];
                     inputs(slot, ps, f);
@@ -931,11 +1031,20 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                     bacc[0] += ab[0];
 #pragma unroll
                     for (int s = 0; s < NST; s++) { fmac_bcast(w0acc0, ab[s], f[0][s]); fmac_bcast(w0acc1, ab[s], f[1][s]); }
+                    TDX_STAMP(19);
                     __syncthreads();                // X[0] and YB are rewritten by the next forward pass
+                    TDX_STAMP(22);
                 }
             }
         }
     }
+#ifdef PINN_STAMPS
+    if (A.psi && lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.psi) + ((size_t)blockIdx.x * C::WAVES + part) * 24;
+        for (int i = 0; i < 24; i++) dbg[i] = st_acc[i];
+    }
+#endif
+#undef TDX_STAMP
     // =========================== block reduction ===========================
     __syncthreads();
     constexpr int PT = Lay::size;
@@ -980,7 +1089,7 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     if (threadIdx.x == 3) out[Lay::bout] = sc[3];
 }
 
-template <int ACT>
+template <int ACT, int VAR = 0>
 hipError_t launch_trunkDx_t(const float* theta, __bf16* wpk, const TrunkArgs& A, int grid, hipStream_t st)
 {
     using C1 = MCfg<128, 4>;
@@ -989,7 +1098,7 @@ hipError_t launch_trunkDx_t(const float* theta, __bf16* wpk, const TrunkArgs& A,
     hipLaunchKernelGGL((k_pack_weights<128, 4, true>), dim3((nfrag + 255) / 256), dim3(256), 0, st, theta, wpk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    auto kern = k_trunkDx<ACT>;
+    auto kern = k_trunkDx<ACT, VAR>;
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1035,6 +1144,11 @@ bool launch_trunk_deep_128(int act, bool x3, int variant, const float* theta, vo
 {
     __bf16* wpk = reinterpret_cast<__bf16*>(packed_weights);
     if (x3) {   // BASELINE config 1 (4x128 fp32-grade): k_trunkDx
+        if (act == ACT_TANH && (variant == 13 || variant == 14)) {   // measurement variants (tools/kbench.py): VAR = variant - 12
+            *err = variant == 13 ? launch_trunkDx_t<ACT_TANH, 1>(theta, wpk, A, grid, st)
+                                 : launch_trunkDx_t<ACT_TANH, 2>(theta, wpk, A, grid, st);
+            return true;
+        }
         *err = act == ACT_TANH ? launch_trunkDx_t<ACT_TANH>(theta, wpk, A, grid, st)
                                : launch_trunkDx_t<ACT_SIGMOID>(theta, wpk, A, grid, st);
         return true;

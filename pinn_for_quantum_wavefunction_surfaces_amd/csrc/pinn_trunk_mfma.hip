@@ -19,7 +19,8 @@ bool mfma_trunk_supported(int H, int L) { return (H == 64 || H == 128) && (L == 
 bool mfma_x3_supported(int H, int L) { return (H == 64 || H == 128) && (L == 2 || L == 4); }
 
 // measurement switch (tools/kbench.py): PINN_MFMA_VARIANT = 0 (default), 3 (the per-pass kernel k_trunk_mfma2 where a
-// merged-pass kernel is the default) or 11.. (variants of k_trunkD).  Read ONCE per process (round 4; it was a getenv per
+// merged-pass kernel is the default) 11 / 12 (k_trunkD / k_trunk2 with lane-linear exchange slots), 13 / 14 (k_trunkDx with swizzled slots / without the
+// in-place operand pipeline).  Read ONCE per process (round 4; it was a getenv per
 // launch) -- except under PINN_MFMA_VARIANT_LIVE=1, which tools/kbench.py and the tests set to switch variants inside
 // one process.
 static int mfma_variant()

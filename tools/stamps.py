@@ -69,6 +69,8 @@ def main():
     ms = tr.h.profile_read(4)
     d = dbg.cpu().numpy().reshape(-1, NS)
     d = d[d.sum(1) > 0].astype(np.float64)
+    if deep and a["precision"] != "bf16":
+        return report_deep_x3(args, a, d, ms, waves)
     if deep:
         return report_deep(args, a, d, ms, waves)
     trips = (args.points + 15) // 16 / (d.shape[0] / waves)
@@ -100,6 +102,33 @@ def report_deep(args, a, d, ms, waves):
     for i in order:
         print("  %-32s %8.0f %5.1f %%   %8.0f %8.0f" % (names[i], d[:, i].mean() / trips, 100 * d[:, i].mean() / tot,
                                                       lo[:, i].mean() / trips, hi[:, i].mean() / trips))
+    print("  barrier waits in all: %.0f cycles per trip (%.1f %%)" % (bar / trips, 100 * bar / tot))
+
+
+def report_deep_x3(args, a, d, ms, waves):
+    """k_trunkDx: cycles by KIND of phase, summed over the three stages of a tile (forward A | forward B, tail, reverse B |
+    forward A, reverse A)"""
+    import numpy as np
+    trips = (args.points + 15) // 16 / (d.shape[0] / waves)
+    names = {23: "loop top / ring refill", 0: "layer 0 (x3)", 1: "  barrier (x3)",
+             2: "forward GEMM 1 (x3)", 5: "  algebra + stores 1", 3: "forward GEMM 2", 6: "  algebra + stores 2",
+             4: "forward GEMM 3", 7: "  algebra / output sums 3", 8: "  barriers of the forward layers (x9)",
+             9: "tail + last-hidden adjoints (x2)", 10: "  barrier (x2)",
+             11: "weight gradient 3 (x2)", 14: "reverse GEMM 3", 17: "  adjoint algebra 3",
+             12: "weight gradient 2", 15: "reverse GEMM 2", 18: "  adjoint algebra 2",
+             13: "weight gradient 1", 16: "reverse GEMM 1", 19: "  layer-0 adjoints",
+             20: "  barrier before the adjoint stores (x4)", 21: "  adjoint stores (x4)", 22: "  barrier after them / end of pass (x6)"}
+    order = [23, 0, 1, 2, 5, 3, 6, 4, 7, 8, 9, 10, 11, 14, 17, 12, 15, 18, 13, 16, 19, 20, 21, 22]
+    tot = d.sum(1).mean()
+    print("%s: stamped kernel %.4f ms, %d waves, %.1f trips per wave, %.0f cycles per trip (%.2f GHz implied)" % (
+        args.arch, ms, d.shape[0], trips, tot / trips, tot / (ms * 1e6)))
+    w = np.arange(d.shape[0]) % waves
+    lo, hi = d[w < waves // 2], d[w >= waves // 2]
+    print("  %-44s %8s %6s   %8s %8s" % ("phase", "cycles", "%", "waves 0-3", "waves 4-7"))
+    for i in order:
+        print("  %-44s %8.0f %5.1f %%   %8.0f %8.0f" % (names[i], d[:, i].mean() / trips, 100 * d[:, i].mean() / tot,
+                                                      lo[:, i].mean() / trips, hi[:, i].mean() / trips))
+    bar = sum(d[:, i].mean() for i in (1, 8, 10, 20, 22))
     print("  barrier waits in all: %.0f cycles per trip (%.1f %%)" % (bar / trips, 100 * bar / tot))
 
 

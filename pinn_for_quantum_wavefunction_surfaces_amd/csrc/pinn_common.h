@@ -20,6 +20,13 @@ struct TrunkArgs {
     float *Eb, *gb;           // MODE_BWD / MODE_HEAD per-point adjoints
     float* partial;           // [gridDim.x][stride]: trunk grads then 3 loss terms
     int stride;
+    // Tiles (16 points) given to the FIRST half of the grid, -1 = an equal share.  With two resident blocks per CU the
+    // dispatcher puts blocks b and b + grid/2 on one CU, and the one that arrived first wins every issue arbitration:
+    // it runs ~1.7x as fast while both are there and then leaves its partner alone on the CU at a lone block's
+    // efficiency (tools/lifecycle.py: 302 us against 425 us for equal shares of 1M points in k_trunk2<64>).  The host
+    // sets the share that lets both finish together (PINN_OLDER_SHARE); the mapping tile -> block stays a pure
+    // function of (n, grid, share): results remain bitwise reproducible.
+    int64_t tile_split;
 };
 
 // ---- MFMA trunk: bf16 operands, fp32 accumulate (dispatch in pinn_trunk_mfma.hip, kernels in pinn_trunk_merged.hip,
@@ -54,7 +61,7 @@ bool rnet_mfma_supported(int HE, int HG);
 hipError_t launch_rnet_mfma_fwd(int act, const float* thE, const float* R, int64_t n, float* E, float* g,
                                 float* Eu, int grid, hipStream_t st);
 hipError_t launch_rnet_mfma_bwd(int act, const float* thE, const float* R, const float* Eb, const float* gb,
-                                int64_t n, float* part, int stride, int grid, hipStream_t st);
+                                int64_t n, float* part, int stride, int grid, int64_t tile_split, hipStream_t st);
 
 // ---- the 16-wide reference trunk on the matrix pipe (pinn_rnet_mfma.hip, k_trunk16): two blocks per CU,
 // 64 points per block and trip

@@ -1055,6 +1055,7 @@ struct pinn_handle {
     int64_t max_points;
     int PT, PR, P;
     int nbT, nbR;           // persistent grid sizes
+    int cus, bpcT;          // CUs of the device, resident trunk blocks per CU the grid is sized for
     int strideT, strideR;
     float *E, *g, *Eb, *gb; // per-point scratch
     float *partT, *partR;   // per-block partials
@@ -1278,7 +1279,56 @@ static int trunk_grid(const pinn_handle* h, int64_t n, int mode)
         // k_trunk16: the reverse kernel holds two blocks per CU (256 registers), the forward-only
         // sweeps (96-116 registers) four
         return grid16(n, mode == MODE_BWD ? h->nbT / 2 : h->nbT);
+    if (a.precision != PINN_PREC_F32) {     // wide matrix-core kernels: one 16-point tile per block and trip
+        const int64_t t16 = (n + 15) / 16;
+        return (int)(t16 < h->nbT ? t16 : h->nbT);
+    }
     return grid_for(n, h->nbT);
+}
+
+// tiles for the first half of the grid (TrunkArgs::tile_split): an unequal share only when the grid is the full
+// two-blocks-per-CU one, where blocks b and b + grid/2 share a CU.  Shares measured per kernel family on MI355X (round 4,
+// tools/share_sweep.sh, 1M points; +-0.02 off the optimum costs ~1 %): k_trunk2<64> 0.665 (0.426 -> 0.397 ms), k_trunk2s<64>
+// 0.625 (0.265 -> 0.245), k_trunkD<64,4> 0.66 (1.052 -> 0.975), k_trunk16's reverse kernel 0.72 (0.181 -> 0.165: its waves
+// share no barrier, the older block's lead is larger); forward-only sweeps: not measured, equal shares.  PINN_OLDER_SHARE overrides (0.5 = rounds 1-3).
+static int64_t trunk_tile_split(const pinn_handle* h, int64_t n, int grid, int mode)
+{
+    auto read = [] {
+        const char* e = getenv("PINN_OLDER_SHARE");
+        const double v = e ? atof(e) : 0.0;
+        return (v >= 0.5 && v <= 0.9) ? v : 0.0;
+    };
+    // read once per process, except under PINN_MFMA_VARIANT_LIVE=1 (the tests and tools switch it inside one process)
+    static const bool live = [] { const char* e = getenv("PINN_MFMA_VARIANT_LIVE"); return e && e[0] == '1'; }();
+    static const double once = read();
+    const double forced = live ? read() : once;
+    if (grid != 2 * h->cus || mode != MODE_BWD) return -1;
+    const pinn_arch& a = h->arch;
+    double share;
+    if (a.precision == PINN_PREC_F32) {
+        if (!trunk16_mfma_supported(a.H, a.L)) return -1;
+        share = 0.72;
+    } else {
+        share = a.L == 4 ? 0.66 : (a.n_pass == 1 ? 0.625 : 0.665);
+    }
+    if (forced > 0.0) share = forced;
+    const int64_t t16 = (n + 15) / 16;
+    return (int64_t)((double)t16 * share + 0.5);
+}
+
+// the same for the R-net reverse kernel (two 4-wave blocks per CU): PINN_RNET_SHARE overrides
+static int64_t rnet_tile_split(const pinn_handle* h, int64_t n, int grid)
+{
+    auto read = [] {
+        const char* e = getenv("PINN_RNET_SHARE");
+        const double v = e ? atof(e) : 0.0;
+        return (v >= 0.5 && v <= 0.9) ? v : 0.68;     // 53.0 -> 50.0 us per 1M points (rocprofv3, tools/rnet_share_sweep.sh)
+    };
+    static const bool live = [] { const char* e = getenv("PINN_MFMA_VARIANT_LIVE"); return e && e[0] == '1'; }();
+    static const double once = read();
+    const double share = live ? read() : once;
+    if (grid != 2 * h->cus) return -1;
+    return (int64_t)((double)((n + 15) / 16) * share + 0.5);
 }
 
 static int run_trunk(pinn_handle* h, int mode, const float* theta, const TrunkArgs& A, int grid,
@@ -1331,7 +1381,13 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     const int bpc = arch->precision != PINN_PREC_F32
                         ? mfma_blocks_per_cu(arch->H, arch->L, arch->precision == PINN_PREC_BF16X3)
                         : (trunk16_mfma_supported(arch->H, arch->L) ? 4 : 1);
-    h->nbT = (int)(tiles < (int64_t)cus * bpc ? tiles : (int64_t)cus * bpc);
+    // the wide matrix-core kernels take 16-point tiles one at a time: size their grid (and the partial rows) by those,
+    // so that a small batch spreads over the chip instead of queueing 16 tiles behind each other in a few blocks
+    // (4 000 points: 16 blocks x 16 trips = 35 us before, 250 blocks x 1 trip now)
+    const int64_t tilesT = arch->precision != PINN_PREC_F32 ? (max_points + 15) / 16 : tiles;
+    h->nbT = (int)(tilesT < (int64_t)cus * bpc ? tilesT : (int64_t)cus * bpc);
+    h->cus = cus;
+    h->bpcT = bpc;
     h->nbR = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
     h->strideT = h->PT + 3;
     h->strideR = h->PR;
@@ -1495,6 +1551,7 @@ extern "C" int pinn_forward(pinn_handle* h, const float* theta, const float* x, 
     A.n = n; A.a = ham->a; A.b = ham->b; A.c = ham->c; A.P = ham->P; A.out_scale = a.out_scale;
     A.invN = 0.f; A.invN1 = 0.f; A.invN2 = 0.f;
     A.psi = psi; A.lap = lap; A.res = res;
+    A.tile_split = -1;
     if (!run_trunk(h, MODE_FWD, theta, A, trunk_grid(h, n, MODE_FWD), st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L, precision)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_trunk<FWD>", e);
@@ -1528,6 +1585,7 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     A.invN = ham->invN; A.invN1 = ham->invN1; A.invN2 = ham->invN2;
     A.bc_counts = (const long long*)bc_counts;
     A.Eb = h->Eb; A.gb = h->gb; A.partial = h->partT; A.stride = h->strideT;
+    A.tile_split = trunk_tile_split(h, n, gT, trunk_trainable ? MODE_BWD : MODE_HEAD);
 #ifdef PINN_STAMPS
     if (const char* sp = getenv("PINN_STAMP_PTR")) A.psi = (float*)strtoull(sp, nullptr, 16);   // diagnostic build only
 #endif
@@ -1541,7 +1599,8 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
         h->prof_calls++;
     }
     if (rmfma)
-        e = launch_rnet_mfma_bwd(a.act, theta + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st);
+        e = launch_rnet_mfma_bwd(a.act, theta + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR,
+                                 rnet_tile_split(h, n, gR), st);
     else if (!launch_rnet_bwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_bwd", e);

@@ -352,4 +352,30 @@ __device__ __forceinline__ float row16_sum(float v)  // sum over the 16 points o
     return v;
 }
 
+// ------------------------------------------------------------------ which tiles a block takes
+// The grid is two classes of blocks, [0, G0) and [G0, G) with G0 = G / 2; each class stripes its own range of the
+// ntile tiles: block b of a class takes first, first + stride, ... below end.  The first class gets `split` tiles
+// (split < 0: a share proportional to its size, i.e. the plain striping of rounds 1-3 up to the order of the tiles).
+// Why: TrunkArgs::tile_split.  `unit` = points per tile / 16 (split is counted in 16-point tiles).
+struct BlockTiles {
+    int64_t first, end;
+    int stride;
+    __device__ __forceinline__ int64_t count() const { return end > first ? (end - first + stride - 1) / stride : 0; }
+};
+__device__ __forceinline__ BlockTiles block_tiles(int64_t ntile, int64_t split, int unit = 1)
+{
+    const int G = (int)gridDim.x, G0 = G >> 1, b = (int)blockIdx.x;
+    const bool c0 = b < G0;
+    int64_t T0 = 0;
+    if (G0) {
+        T0 = split >= 0 ? (split + unit - 1) / unit : ntile * G0 / G;
+        if (T0 > ntile) T0 = ntile;
+    }
+    BlockTiles t;
+    t.first = c0 ? (int64_t)b : T0 + (b - G0);
+    t.end = c0 ? T0 : ntile;
+    t.stride = c0 ? G0 : G - G0;
+    return t;
+}
+
 }  // namespace

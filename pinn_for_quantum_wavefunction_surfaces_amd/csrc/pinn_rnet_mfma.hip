@@ -195,7 +195,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_rnet_mfma_bwd(const float* __rest
                                                              const float* __restrict__ R,
                                                              const float* __restrict__ Eb,
                                                              const float* __restrict__ gb, int64_t n,
-                                                             float* __restrict__ partial, int stride)
+                                                             float* __restrict__ partial, int stride,
+                                                             int64_t tile_split)
 {
     constexpr RnetLayout Lo{32, 10};
     constexpr int PR = Lo.size();
@@ -224,9 +225,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_rnet_mfma_bwd(const float* __rest
         wacc[a][0] = splat(0.f); wacc[a][1] = splat(0.f);
     }
     const float lead = g == 0 ? 1.0f : 0.0f;
-    const int64_t ntile = (n + 15) / 16, tstep = (int64_t)gridDim.x * kWavesPerBlock;
+    // a block takes kWavesPerBlock consecutive tiles per trip (one per wave); which ones: block_tiles (TrunkArgs::tile_split)
+    const int64_t ntile0 = (n + 15) / 16;
+    const BlockTiles bt = block_tiles((ntile0 + kWavesPerBlock - 1) / kWavesPerBlock, tile_split, kWavesPerBlock);
+    const int64_t tstep = (int64_t)bt.stride * kWavesPerBlock;
+    const int64_t ntile = bt.end * kWavesPerBlock < ntile0 ? bt.end * kWavesPerBlock : ntile0;
     // the next trip's point record (R, E-bar, g-bar) is requested before this trip's arithmetic
-    int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    int64_t tile = bt.first * kWavesPerBlock + wave;
     float Rn = 0.f, ebn = 0.f, gbn = 0.f;
     auto request = [&](int64_t t) {
         const int64_t i = t * 16 + c;
@@ -446,7 +451,9 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
 
     // the point record of the next tile is requested one trip ahead (nothing waits for it until then)
     struct PointRec { float x, y, z, R, E, g; unsigned mk; };
-    const int64_t tstep = (int64_t)gridDim.x * kWavesPerBlock;
+    // a block takes kWavesPerBlock consecutive tiles per trip (one per wave): block_tiles in units of that many tiles
+    const BlockTiles bt = block_tiles((ntile + kWavesPerBlock - 1) / kWavesPerBlock, A.tile_split, kWavesPerBlock);
+    const int64_t tstep = (int64_t)bt.stride * kWavesPerBlock, tlast = bt.end * kWavesPerBlock < ntile ? bt.end * kWavesPerBlock : ntile;
     auto load_rec = [&](int64_t tl) {
         int64_t id = tl * 16 + c;
         id = (tl < ntile && id < A.n) ? id : A.n - 1;
@@ -455,12 +462,12 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
         r.mk = (MODE != MODE_FWD && A.mask) ? A.mask[id] : 0u;
         return r;
     };
-    PointRec nxt = load_rec((int64_t)blockIdx.x * kWavesPerBlock + wave);
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < ntile; tile += tstep) {
+    PointRec nxt = load_rec(bt.first * kWavesPerBlock + wave);
+    for (int64_t tile = bt.first * kWavesPerBlock + wave; tile < tlast; tile += tstep) {
         const int64_t idx = tile * 16 + c;
         const bool valid = idx < A.n;
         const PointRec cur = nxt;
-        if (tile + tstep < ntile) nxt = load_rec(tile + tstep);
+        if (tile + tstep < tlast) nxt = load_rec(tile + tstep);
         const float xv = cur.x, yv = cur.y, zv = cur.z, Rv = cur.R;
         const float Ev = cur.E, gv = cur.g;
         const float m1 = float(cur.mk & 1), m2 = float((cur.mk >> 1) & 1);
@@ -714,12 +721,12 @@ hipError_t launch_rnet_mfma_fwd(int act, const float* thE, const float* R, int64
 }
 
 hipError_t launch_rnet_mfma_bwd(int act, const float* thE, const float* R, const float* Eb, const float* gb,
-                                int64_t n, float* part, int stride, int grid, hipStream_t st)
+                                int64_t n, float* part, int stride, int grid, int64_t tile_split, hipStream_t st)
 {
     if (act == ACT_SIGMOID)
-        hipLaunchKernelGGL(k_rnet_mfma_bwd<ACT_SIGMOID>, dim3(grid), dim3(kBlock), 0, st, thE, R, Eb, gb, n, part, stride);
+        hipLaunchKernelGGL(k_rnet_mfma_bwd<ACT_SIGMOID>, dim3(grid), dim3(kBlock), 0, st, thE, R, Eb, gb, n, part, stride, tile_split);
     else
-        hipLaunchKernelGGL(k_rnet_mfma_bwd<ACT_TANH>, dim3(grid), dim3(kBlock), 0, st, thE, R, Eb, gb, n, part, stride);
+        hipLaunchKernelGGL(k_rnet_mfma_bwd<ACT_TANH>, dim3(grid), dim3(kBlock), 0, st, thE, R, Eb, gb, n, part, stride, tile_split);
     return hipGetLastError();
 }
 

@@ -143,15 +143,17 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     }
     const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
-    const int64_t iters = (ntile + gridDim.x - 1) / gridDim.x;   // same for every block: barriers match
+    const BlockTiles bt = block_tiles(ntile, A.tile_split);      // this block's tiles: first, first + stride, ... < end
+    const int64_t tfirst = bt.first, tend = bt.end, iters = bt.count();
+    const int tstride = bt.stride;
 
     constexpr int RB = C::RB, RECF = C::RECF;
     float* ring = reinterpret_cast<float*>(lds_raw + C::OFF_R);
     struct PointRec { float x, y, z, R, E, g; unsigned mk; };
     auto load_rec = [&](int64_t b) {
-        const int64_t tl = (b * RB + 4 * part + g) * gridDim.x + blockIdx.x;
+        const int64_t tl = tfirst + (b * RB + 4 * part + g) * tstride;
         int64_t id = tl * 16 + c;
-        id = (tl < ntile && id < A.n) ? id : A.n - 1;
+        id = (tl < tend && id < A.n) ? id : A.n - 1;
         PointRec r;
         r.x = A.x[id]; r.y = A.y[id]; r.z = A.z[id]; r.R = A.R[id]; r.E = A.E[id]; r.g = A.g[id];
         r.mk = A.mask ? A.mask[id] : 0u;
@@ -251,9 +253,9 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
 #define TD_STAMP(i) do { } while (0)
 #endif
     for (int64_t itx = 0; itx < iters; itx++) {
-        const int64_t tile = itx * gridDim.x + blockIdx.x;
+        const int64_t tile = tfirst + itx * tstride;
         const int64_t idx = tile * 16 + c;
-        const bool valid = tile < ntile && idx < A.n;
+        const bool valid = tile < tend && idx < A.n;
         const int slot = (int)(itx % RB);
         if (slot == 0) {
             if (itx) __syncthreads();           // the last reverse step of the previous trip read the old batch

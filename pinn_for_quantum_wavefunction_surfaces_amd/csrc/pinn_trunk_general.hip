@@ -206,14 +206,15 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
     // per-point sums are taken by ONE lane group of ONE wave of the group
     const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
-    const int64_t tstride = (int64_t)gridDim.x * C::GROUPS;
-    const int64_t iters = (ntile + tstride - 1) / tstride;   // same for every wave: barriers match
+    // a block takes GROUPS consecutive tiles per trip (one per group): block_tiles in units of GROUPS tiles
+    const BlockTiles bt = block_tiles((ntile + C::GROUPS - 1) / C::GROUPS, A.tile_split, C::GROUPS);
+    const int64_t iters = bt.count();   // same for every wave of the block: barriers match
 
     // the point record of the NEXT tile is requested one trip ahead (7 loads per lane that nothing waits
     // for until the next trip): without this every trip opened with an exposed round trip to L2/HBM
     struct PointRec { float x, y, z, R, E, g; unsigned mk; };
     auto load_rec = [&](int64_t itn) {
-        const int64_t tl = itn * tstride + (int64_t)blockIdx.x * C::GROUPS + grp;
+        const int64_t tl = (bt.first + itn * bt.stride) * C::GROUPS + grp;
         int64_t id = tl * 16 + c;
         id = (tl < ntile && id < A.n) ? id : A.n - 1;
         PointRec r;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
     };
     PointRec nxt = load_rec(0);
     for (int64_t itx = 0; itx < iters; itx++) {
-        const int64_t tile = itx * tstride + (int64_t)blockIdx.x * C::GROUPS + grp;
+        const int64_t tile = (bt.first + itx * bt.stride) * C::GROUPS + grp;
         const int64_t idx = tile * 16 + c;
         const bool valid = tile < ntile && idx < A.n;
         const PointRec cur = nxt;

@@ -50,6 +50,9 @@ template <int H, int ACT, bool SWZ = true>
 __global__ __launch_bounds__(T2Cfg<H>::WAVES * 64, T2Cfg<H>::OCC * T2Cfg<H>::WAVES / 4)
 void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, TrunkArgs A)
 {
+#ifdef PINN_STAMPS
+    const unsigned long long life0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same clock on every CU
+#endif
     using C = T2Cfg<H>;
     using Lay = TrunkLayout<H, 2>;
     constexpr int HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB;
@@ -115,16 +118,18 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     }
     const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
-    const int64_t iters = (ntile + gridDim.x - 1) / gridDim.x;   // same for every block: barriers match
+    const BlockTiles bt = block_tiles(ntile, A.tile_split);      // this block's tiles: first, first + stride, ... < end
+    const int64_t tfirst = bt.first, tend = bt.end, iters = bt.count();
+    const int tstride = bt.stride;
 
     // ring batch b covers trips b*RB .. b*RB + RB-1; this lane's point of it: trip b*RB + 4*part + g, column c
     constexpr int RB = C::RB, RECF = C::RECF;
     float* ring = reinterpret_cast<float*>(lds_raw + C::OFF_R);
     struct PointRec { float x, y, z, R, E, g; unsigned mk; };
     auto load_rec = [&](int64_t b) {
-        const int64_t tl = (b * RB + 4 * part + g) * gridDim.x + blockIdx.x;
+        const int64_t tl = tfirst + (b * RB + 4 * part + g) * tstride;
         int64_t id = tl * 16 + c;
-        id = (tl < ntile && id < A.n) ? id : A.n - 1;
+        id = (tl < tend && id < A.n) ? id : A.n - 1;
         PointRec r;
         r.x = A.x[id]; r.y = A.y[id]; r.z = A.z[id]; r.R = A.R[id]; r.E = A.E[id]; r.g = A.g[id];
         r.mk = A.mask ? A.mask[id] : 0u;
@@ -155,6 +160,9 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
 
     // -DPINN_STAMPS (diagnostic build, tools/stamps.py): per-wave cycle totals of the phases and of the
     // barrier waits between them, written to the buffer passed in A.psi (unused by this mode)
+#ifdef PINN_STAMPS
+    const unsigned long long life1 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef PINN_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #define T2_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
@@ -187,9 +195,9 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     int xset = 0;
     for (int64_t itx = 0; itx < iters; itx++) {
         T2_STAMP(7);
-        const int64_t tile = itx * gridDim.x + blockIdx.x;
+        const int64_t tile = tfirst + itx * tstride;
         const int64_t idx = tile * 16 + c;
-        const bool valid = tile < ntile && idx < A.n;
+        const bool valid = tile < tend && idx < A.n;
         if (itx % RB == 0) {
             // refill: the last reads of the previous batch (P1, P3 of the previous trip) lie before that
             // trip's third barrier, which every wave has passed
@@ -349,6 +357,9 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         T2_STAMP(6);
     }
 #ifdef PINN_STAMPS
+    const unsigned long long life2 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef PINN_STAMPS
     if (A.psi && lane == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.psi) + ((size_t)blockIdx.x * C::WAVES + part) * 8;
         for (int i = 0; i < 8; i++) dbg[i] = st_acc[i];
@@ -395,6 +406,17 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     }
     if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
     if (threadIdx.x == 3) out[Lay::bout] = sc[3];
+#ifdef PINN_STAMPS
+    if (A.psi && lane == 0) {   // life cycle of this wave on the 100 MHz clock: entry, first tile, last tile done, exit (tools/lifecycle.py)
+        unsigned long long* lf = reinterpret_cast<unsigned long long*>(A.psi) + (size_t)4096 * C::WAVES * 8
+                                 + ((size_t)blockIdx.x * C::WAVES + part) * 6;
+        lf[0] = life0; lf[1] = life1; lf[2] = life2; lf[3] = __builtin_amdgcn_s_memrealtime();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        lf[4] = hw; lf[5] = xcc;
+    }
+#endif
 }
 
 template <int H, int ACT, bool SWZ = true>
@@ -517,7 +539,9 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     }
     const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
-    const int64_t iters = (ntile + NTL * gridDim.x - 1) / (NTL * gridDim.x);   // same for every block: barriers match
+    const BlockTiles bt = block_tiles(ntile, A.tile_split);      // this block's tiles: first, first + stride, ... < end
+    const int64_t tfirst = bt.first, tend = bt.end, iters = (bt.count() + NTL - 1) / NTL;   // NTL tiles per trip
+    const int tstride = bt.stride;
 
     // ring batch b covers the block's tiles b*RB .. b*RB + RB-1 (NTL per trip); this lane's point of it: tile
     // b*RB + 4*part + g, column c
@@ -525,9 +549,9 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     float* ring = reinterpret_cast<float*>(lds_raw + C::OFF_R);
     struct PointRec { float x, y, z, R, E, g; unsigned mk; };
     auto load_rec = [&](int64_t b) {
-        const int64_t tl = (b * RB + 4 * part + g) * gridDim.x + blockIdx.x;
+        const int64_t tl = tfirst + (b * RB + 4 * part + g) * tstride;
         int64_t id = tl * 16 + c;
-        id = (tl < ntile && id < A.n) ? id : A.n - 1;
+        id = (tl < tend && id < A.n) ? id : A.n - 1;
         PointRec r;
         r.x = A.x[id]; r.y = A.y[id]; r.z = A.z[id]; r.R = A.R[id]; r.E = A.E[id]; r.g = A.g[id];
         r.mk = A.mask ? A.mask[id] : 0u;
@@ -590,9 +614,9 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     int xset = 0;
     for (int64_t itx = 0; itx < iters; itx++) {
         T2_STAMP(7);
-        const int64_t tile = (NTL * itx) * gridDim.x + blockIdx.x;      // (TT: the first of the trip's two tiles)
+        const int64_t tile = tfirst + (NTL * itx) * tstride;           // (TT: the first of the trip's two tiles)
         const int64_t idx = tile * 16 + c;
-        const bool valid = tile < ntile && idx < A.n;
+        const bool valid = tile < tend && idx < A.n;
         const int slot0 = (int)((NTL * itx) % RB);                       // ring slot of that tile
         if (slot0 == 0) {
             // refill: the last reads of the previous batch (P1, P3 of the previous trip) lie before that
@@ -700,8 +724,8 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
                 const float* rp = ring + ((slot0 + tl) * 16 + c) * RECF;
                 const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4),
                             r2 = *reinterpret_cast<const f32x4*>(rp + 8);
-                const int64_t tile_t = tile + (int64_t)tl * gridDim.x, idx_t = tile_t * 16 + c;
-                const bool valid_t = tile_t < ntile && idx_t < A.n;
+                const int64_t tile_t = tile + (int64_t)tl * tstride, idx_t = tile_t * 16 + c;
+                const bool valid_t = tile_t < tend && idx_t < A.n;
                 const unsigned mk = (unsigned)r2[3];
                 tail<float>(A.out_scale * Sv + bout, A.out_scale * Sl, r2[2], r2[1], r0[0] + A.P * r1[0], r0[SLP] + A.P * r1[SLP],
                             r2[0], A.a, A.b, A.c, float(mk & 1), float((mk >> 1) & 1), A.invN, invN1, invN2,

@@ -968,6 +968,46 @@ def test_bitwise_reproducible_with_co_resident_blocks(H, L, prec):
         assert (runs[k] == runs[0]).all(), "run %d differs in %d entries" % (k, int((runs[k] != runs[0]).sum()))
 
 
+@pytest.mark.parametrize("H,L,prec", [(16, 2, "f32"), (64, 2, "bf16"), (64, 2, "bf16-B"), (64, 4, "bf16"), (128, 2, "bf16")])
+def test_unequal_tile_shares_only_reorder_the_sums(H, L, prec, monkeypatch):
+    """Round 4: at a full two-blocks-per-CU grid the first half of the blocks (the ones that reach a CU first and win its
+    issue arbitration) takes a larger share of the tiles (TrunkArgs::tile_split, PINN_OLDER_SHARE / PINN_RNET_SHARE).  The
+    share must move tiles between blocks and nothing else: every share -- equal, the default, an extreme one -- gives the
+    same losses and gradient up to the order of the fp32 block sums, on a ragged batch (one dropped or doubled tile of
+    the 8 193 would move a loss by 1.2e-4).  (H = 128: one block per CU, the share is not used -- same check.)"""
+    n = 131072 + 7
+    form_b = prec.endswith("-B")
+    prec = prec.split("-")[0]
+    A = O.arch(H=H, L=L, act=1, n_pass=1, out_scale=2.0) if form_b else O.arch(H=H, L=L, act=1)
+    rng = np.random.default_rng(77 + H + L)
+    off, sz = O.tensor_layout(A)
+    theta = np.zeros(O.param_count(A))
+    fan = [2, 2] + [H, H] * (L - 1) + [H, H, 1, 1, 32, 32, 32, 32, 1, 1, 10, 10]
+    for o, s_, fi in zip(off, sz, fan):
+        theta[o:o + s_] = rng.uniform(-1, 1, s_) / np.sqrt(fi)
+    x, y, z = rng.uniform(-18, 18, (3, n))
+    R = rng.uniform(0.2, 3, n)
+    mask = rng.integers(0, 4, n).astype(np.uint8)
+    pr = {"f32": capi.PINN_PREC_F32, "bf16": capi.PINN_PREC_BF16}[prec]
+    h = capi.Handle(capi.Arch(H, L, 32, 10, 1, 1, 2.0, pr) if form_b else capi.Arch(H, L, 32, 10, 1, 2, 1.0, pr), 0, n)
+    f = pkg.model.FORMULATION_B if form_b else pkg.model.FORMULATION_A
+    P = O.param_count(A)
+    out = {}
+    for share in ("0.5", None, "0.85"):
+        for var in ("PINN_OLDER_SHARE", "PINN_RNET_SHARE"):
+            if share is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, share)
+        out[share] = run_loss_grad(h, f, theta, x, y, z, R, mask).astype(np.float64)
+        assert np.isfinite(out[share]).all()
+    ref = out["0.5"]
+    for share in (None, "0.85"):
+        for k in range(3):
+            assert abs(out[share][P + k] / ref[P + k] - 1) < 2e-5, (share, k)
+        assert rel(out[share][:P], ref[:P]) < 2e-5, share
+
+
 @pytest.mark.parametrize("H,L,form,act", [(64, 2, "B", 1), (128, 2, "A", 0), (128, 2, "B", 1),
                                            (64, 4, "A", 1), (128, 4, "A", 1), (128, 4, "B", 0)])
 def test_mfma_bf16_matches_oracle(H, L, form, act):

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Life cycle of the waves of one k_trunk2 launch on the chip-wide 100 MHz clock (diagnostic -DPINN_STAMPS build,
+`python tools/stamps.py --build` first): when each wave entered the kernel, reached its first tile, finished its last
+tile and left, relative to the first wave's entry.
+
+    python tools/lifecycle.py [--points 4000]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pinn_for_quantum_wavefunction_surfaces_amd")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=4000)
+    ap.add_argument("--arch", default="wide64")
+    args = ap.parse_args()
+    os.environ["PINN_HIP_LIB"] = os.path.join(PKG, "libpinn_hip_stamps.so")
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    sys.argv = ["bench.py"]
+    spec.loader.exec_module(bench)
+    import pinn_for_quantum_wavefunction_surfaces_amd as pkg
+    a = bench.ARCHS[args.arch]
+    dev = torch.device("cuda", 0)
+    params = pkg.set_params()
+    torch.manual_seed(12345)
+    m = pkg.NN_ion(params, a["H"], a["HE"], a["HG"], n_hidden=a["L"], act=a["act_name"], precision=a["precision"]).to(dev)
+    tr = pkg.Trainer(m, params, n_points=args.points, lr=8e-3, seed=12345, device=dev)
+    waves = a["H"] // 16
+    dbg = torch.zeros(4096 * waves * 14, device=dev, dtype=torch.int64)
+    for _ in range(50):
+        tr.step()
+    torch.cuda.synchronize()
+    os.environ["PINN_STAMP_PTR"] = "%x" % dbg.data_ptr()
+    tr.h.profile_enable(4)
+    for _ in range(4):
+        tr.step()
+    torch.cuda.synchronize()
+    ms = tr.h.profile_read(4)
+    lf = dbg.cpu().numpy()[4096 * waves * 8:].reshape(-1, 6)
+    lf = lf[lf[:, 0] > 0].astype(np.float64)
+    hw, xcc = lf[:, 4].astype(np.int64), lf[:, 5].astype(np.int64)
+    lf = lf[:, :4]
+    t0 = lf[:, 0].min()
+    us = (lf - t0) / 100.0
+    print("%s, %d points: kernel %.1f us by HIP events (with the weight pack); %d waves wrote a record" % (args.arch, args.points, 1e3 * ms, len(us)))
+    for k, name in enumerate(["kernel entry", "first tile starts", "last tile done", "exit"]):
+        print("  %-18s min %7.2f  median %7.2f  max %7.2f us after the first wave's entry" % (name, us[:, k].min(), np.median(us[:, k]), us[:, k].max()))
+    d = us[:, 1:] - us[:, :-1]
+    for k, name in enumerate(["prologue", "tile loop", "epilogue"]):
+        print("  %-18s min %7.2f  median %7.2f  max %7.2f us per wave" % (name, d[:, k].min(), np.median(d[:, k]), d[:, k].max()))
+
+
+    # who shares a CU: HW_ID bits (gfx9 layout) wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13; XCC_ID 3:0
+    cu = ((xcc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+    simd = (hw >> 4) & 3
+    blocks = np.arange(len(us)) // waves
+    print("  distinct CUs %d, blocks %d; SIMD ids seen %s" % (len(set(cu.tolist())), blocks.max() + 1, sorted(set(simd.tolist()))))
+    done = {}
+    for b in range(blocks.max() + 1):
+        m = blocks == b
+        done.setdefault(int(cu[m][0]), []).append((float(us[m, 2].max()), float(us[m, 0].min()), b))
+    pairs = [sorted(v) for v in done.values() if len(v) == 2]
+    if pairs:
+        first = np.array([p[0][0] for p in pairs]); second = np.array([p[1][0] for p in pairs])
+        print("  CUs with two blocks: %d; the block that finishes its tiles first: median %.1f us (min %.1f, max %.1f); the other: median %.1f us (min %.1f, max %.1f)" % (
+            len(pairs), np.median(first), first.min(), first.max(), np.median(second), second.min(), second.max()))
+        early = np.array([p[0][1] < p[1][1] for p in pairs])
+        print("  the first finisher is the block that ENTERED first on %d of %d CUs; block-index distance of the partners: %s" % (
+            early.sum(), len(pairs), sorted(set(abs(p[0][2] - p[1][2]) for p in pairs))[:8]))
+    h, edges = np.histogram(us[:, 2], bins=12)
+    print("  histogram of 'last tile done' (us): " + "  ".join("%.0f-%.0f:%d" % (edges[i], edges[i + 1], h[i]) for i in range(len(h))))
+
+
+if __name__ == "__main__":
+    main()

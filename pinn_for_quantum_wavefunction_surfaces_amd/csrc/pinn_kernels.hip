@@ -1278,7 +1278,7 @@ static int trunk_grid(const pinn_handle* h, int64_t n, int mode)
     if (a.precision == PINN_PREC_F32 && trunk16_mfma_supported(a.H, a.L))
         // k_trunk16: the reverse kernel holds two blocks per CU (256 registers), the forward-only
         // sweeps (96-116 registers) four
-        return grid16(n, mode == MODE_BWD ? h->nbT / 2 : h->nbT);
+        return grid16(n, mode == MODE_BWD && h->nbT > 2 * h->cus ? 2 * h->cus : h->nbT);
     if (a.precision != PINN_PREC_F32) {     // wide matrix-core kernels: one 16-point tile per block and trip
         const int64_t t16 = (n + 15) / 16;
         return (int)(t16 < h->nbT ? t16 : h->nbT);
@@ -1384,11 +1384,16 @@ extern "C" int pinn_create(const pinn_arch* arch, int device, int64_t max_points
     // the wide matrix-core kernels take 16-point tiles one at a time: size their grid (and the partial rows) by those,
     // so that a small batch spreads over the chip instead of queueing 16 tiles behind each other in a few blocks
     // (4 000 points: 16 blocks x 16 trips = 35 us before, 250 blocks x 1 trip now)
-    const int64_t tilesT = arch->precision != PINN_PREC_F32 ? (max_points + 15) / 16 : tiles;
+    // (the 16-wide reference trunk and the R-net kernels on the matrix pipe: 64 points per block and trip -- round 4: they
+    // were sized by 256-point units too, 8 blocks for a 4 000-point reverse sweep)
+    const int64_t tiles64 = (max_points + 63) / 64;
+    const int64_t tilesT = arch->precision != PINN_PREC_F32 ? (max_points + 15) / 16
+                           : (trunk16_mfma_supported(arch->H, arch->L) ? tiles64 : tiles);
     h->nbT = (int)(tilesT < (int64_t)cus * bpc ? tilesT : (int64_t)cus * bpc);
     h->cus = cus;
     h->bpcT = bpc;
-    h->nbR = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
+    const int64_t tilesR = rnet_mfma_supported(arch->HE, arch->HG) ? tiles64 : tiles;
+    h->nbR = (int)(tilesR < (int64_t)cus * 2 ? tilesR : (int64_t)cus * 2);
     h->strideT = h->PT + 3;
     h->strideR = h->PR;
     HIPCHK(h, hipMalloc(&h->E, sizeof(float) * max_points));

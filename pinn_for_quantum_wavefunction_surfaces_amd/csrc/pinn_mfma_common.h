@@ -352,6 +352,27 @@ __device__ __forceinline__ float row16_sum(float v)  // sum over the 16 points o
     return v;
 }
 
+// ------------------------------------------------------------------ life cycle of a wave (diagnostic build only)
+// -DPINN_STAMPS, tools/lifecycle.py: entry, first tile, last tile done, exit on the chip-wide 100 MHz clock, and the
+// hardware id of the CU the wave ran on; record (block * waves + wave) behind the phase-stamp region of the buffer in A.psi
+#ifdef PINN_STAMPS
+#define PINN_LIFE_NOW() __builtin_amdgcn_s_memrealtime()
+__device__ __forceinline__ void life_write(float* psi, int waves, int wave, unsigned long long t0, unsigned long long t1,
+                                           unsigned long long t2)
+{
+    if (!psi || (threadIdx.x & 63) != 0) return;
+    unsigned long long* lf = reinterpret_cast<unsigned long long*>(psi) + (size_t)4096 * 8 * 8
+                             + ((size_t)blockIdx.x * waves + wave) * 6;
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    lf[0] = t0; lf[1] = t1; lf[2] = t2; lf[3] = __builtin_amdgcn_s_memrealtime(); lf[4] = hw; lf[5] = xcc;
+}
+#else
+#define PINN_LIFE_NOW() 0ull
+__device__ __forceinline__ void life_write(float*, int, int, unsigned long long, unsigned long long, unsigned long long) {}
+#endif
+
 // ------------------------------------------------------------------ which tiles a block takes
 // The grid is two classes of blocks, [0, G0) and [G0, G) with G0 = G / 2; each class stripes its own range of the
 // ntile tiles: block b of a class takes first, first + stride, ... below end.  The first class gets `split` tiles

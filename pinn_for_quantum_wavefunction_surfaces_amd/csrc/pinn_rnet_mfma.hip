@@ -383,6 +383,7 @@ __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c)
 template <int ACT, int NPASS, int MODE>
 __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(const float* __restrict__ theta, TrunkArgs A)
 {
+    const unsigned long long life0 = PINN_LIFE_NOW();
     using Lay = TrunkLayout<16, 2>;
     constexpr int PT = Lay::size;
     constexpr int PITCH = 24;                 // bf16 per image row: 16 neurons + 8
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
         return r;
     };
     PointRec nxt = load_rec(bt.first * kWavesPerBlock + wave);
+    const unsigned long long life1 = PINN_LIFE_NOW();
     for (int64_t tile = bt.first * kWavesPerBlock + wave; tile < tlast; tile += tstep) {
         const int64_t idx = tile * 16 + c;
         const bool valid = idx < A.n;
@@ -637,6 +639,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
     }
 
     if (MODE == MODE_FWD) return;
+    const unsigned long long life2 = PINN_LIFE_NOW();
     // =========================== block reduction ===========================
     const float s0 = row16_sum(xg_sum(acc_pde)), s1r = row16_sum(xg_sum(acc_bc1)),
                 s2r = row16_sum(xg_sum(acc_bc2)), s3r = row16_sum(xg_sum(acc_bout));
@@ -680,6 +683,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
         for (int k = threadIdx.x; k < PT; k += kBlock) out[k] = 0.0f;
     }
     if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
+    life_write(A.psi, kWavesPerBlock, wave, life0, life1, life2);
 }
 #undef T16_B0
 #undef T16_B1

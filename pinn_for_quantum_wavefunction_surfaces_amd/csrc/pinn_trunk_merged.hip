@@ -50,9 +50,7 @@ template <int H, int ACT, bool SWZ = true>
 __global__ __launch_bounds__(T2Cfg<H>::WAVES * 64, T2Cfg<H>::OCC * T2Cfg<H>::WAVES / 4)
 void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, TrunkArgs A)
 {
-#ifdef PINN_STAMPS
-    const unsigned long long life0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same clock on every CU
-#endif
+    const unsigned long long life0 = PINN_LIFE_NOW();
     using C = T2Cfg<H>;
     using Lay = TrunkLayout<H, 2>;
     constexpr int HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB;
@@ -160,9 +158,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
 
     // -DPINN_STAMPS (diagnostic build, tools/stamps.py): per-wave cycle totals of the phases and of the
     // barrier waits between them, written to the buffer passed in A.psi (unused by this mode)
-#ifdef PINN_STAMPS
-    const unsigned long long life1 = __builtin_amdgcn_s_memrealtime();
-#endif
+    const unsigned long long life1 = PINN_LIFE_NOW();
 #ifdef PINN_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #define T2_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
@@ -356,9 +352,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         xset ^= 1;
         T2_STAMP(6);
     }
-#ifdef PINN_STAMPS
-    const unsigned long long life2 = __builtin_amdgcn_s_memrealtime();
-#endif
+    const unsigned long long life2 = PINN_LIFE_NOW();
 #ifdef PINN_STAMPS
     if (A.psi && lane == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.psi) + ((size_t)blockIdx.x * C::WAVES + part) * 8;
@@ -406,17 +400,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     }
     if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
     if (threadIdx.x == 3) out[Lay::bout] = sc[3];
-#ifdef PINN_STAMPS
-    if (A.psi && lane == 0) {   // life cycle of this wave on the 100 MHz clock: entry, first tile, last tile done, exit (tools/lifecycle.py)
-        unsigned long long* lf = reinterpret_cast<unsigned long long*>(A.psi) + (size_t)4096 * C::WAVES * 8
-                                 + ((size_t)blockIdx.x * C::WAVES + part) * 6;
-        lf[0] = life0; lf[1] = life1; lf[2] = life2; lf[3] = __builtin_amdgcn_s_memrealtime();
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        lf[4] = hw; lf[5] = xcc;
-    }
-#endif
+    life_write(A.psi, C::WAVES, part, life0, life1, life2);
 }
 
 template <int H, int ACT, bool SWZ = true>

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Life cycle of the waves of one k_trunk2 launch on the chip-wide 100 MHz clock (diagnostic -DPINN_STAMPS build,
+"""Life cycle of the waves of one k_trunk2 / k_trunk16 launch (--arch wide64 | wide128 | ref16) on the chip-wide 100 MHz clock (diagnostic -DPINN_STAMPS build,
 `python tools/stamps.py --build` first): when each wave entered the kernel, reached its first tile, finished its last
 tile and left, relative to the first wave's entry.
 
@@ -33,8 +33,9 @@ def main():
     torch.manual_seed(12345)
     m = pkg.NN_ion(params, a["H"], a["HE"], a["HG"], n_hidden=a["L"], act=a["act_name"], precision=a["precision"]).to(dev)
     tr = pkg.Trainer(m, params, n_points=args.points, lr=8e-3, seed=12345, device=dev)
-    waves = a["H"] // 16
-    dbg = torch.zeros(4096 * waves * 14, device=dev, dtype=torch.int64)
+    waves = max(a["H"] // 16, 4)                 # waves per block of the trunk kernel (k_trunk16: 4)
+    OFF = 4096 * 8 * 8                           # life records sit behind the phase-stamp region (csrc/pinn_mfma_common.h)
+    dbg = torch.zeros(OFF + 4096 * 8 * 6, device=dev, dtype=torch.int64)
     for _ in range(50):
         tr.step()
     torch.cuda.synchronize()
@@ -44,7 +45,7 @@ def main():
         tr.step()
     torch.cuda.synchronize()
     ms = tr.h.profile_read(4)
-    lf = dbg.cpu().numpy()[4096 * waves * 8:].reshape(-1, 6)
+    lf = dbg.cpu().numpy()[OFF:].reshape(-1, 6)
     lf = lf[lf[:, 0] > 0].astype(np.float64)
     hw, xcc = lf[:, 4].astype(np.int64), lf[:, 5].astype(np.int64)
     lf = lf[:, :4]

@@ -9,6 +9,19 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HEAD = 2 };
 
+// Which share of the 16-point tiles each CLASS of blocks takes.  With K resident blocks per CU the dispatcher puts blocks
+// b, b + G/K, b + 2G/K, ... of a grid of G on one CU, and the waves that arrived first win every issue arbitration on their
+// SIMDs: of two blocks with equal shares of 1M points the first finishes after 302 us and then leaves its partner alone on
+// the CU, at a lone block's efficiency, until 425 us (k_trunk2<64>); of four (k_trunk16's forward-only sweep) the blocks
+// finish after 29, 48, 69 and 87 us (tools/lifecycle.py, profiles/r04_block_shares.md).  Class c = blocks [c G/K, (c+1) G/K)
+// stripes the tiles [bound[c-1], bound[c]) (bound[-1] = 0, bound[K-1] = all); the host sets the bounds that let the
+// classes finish together when the grid is the full K-per-CU one, nclass = 0 (equal shares) otherwise.  The map tile ->
+// block stays a pure function of (n, grid, shares): results remain bitwise reproducible.
+struct TileShares {
+    int nclass;               // 0: equal shares; 2 or 4
+    int64_t bound[3];         // upper tile bounds of classes 0 .. nclass-2, in 16-point tiles
+};
+
 struct TrunkArgs {
     const float *x, *y, *z, *R;
     const float *E, *g;       // from k_rnet_fwd
@@ -20,13 +33,7 @@ struct TrunkArgs {
     float *Eb, *gb;           // MODE_BWD / MODE_HEAD per-point adjoints
     float* partial;           // [gridDim.x][stride]: trunk grads then 3 loss terms
     int stride;
-    // Tiles (16 points) given to the FIRST half of the grid, -1 = an equal share.  With two resident blocks per CU the
-    // dispatcher puts blocks b and b + grid/2 on one CU, and the one that arrived first wins every issue arbitration:
-    // it runs ~1.7x as fast while both are there and then leaves its partner alone on the CU at a lone block's
-    // efficiency (tools/lifecycle.py: 302 us against 425 us for equal shares of 1M points in k_trunk2<64>).  The host
-    // sets the share that lets both finish together (PINN_OLDER_SHARE); the mapping tile -> block stays a pure
-    // function of (n, grid, share): results remain bitwise reproducible.
-    int64_t tile_split;
+    TileShares shares;        // which tiles a block takes (see TileShares)
 };
 
 // ---- MFMA trunk: bf16 operands, fp32 accumulate (dispatch in pinn_trunk_mfma.hip, kernels in pinn_trunk_merged.hip,
@@ -59,9 +66,9 @@ bool launch_trunk_general_128x4(int act, int npass, int mode, bool x3, const flo
 // ---- R-only nets on the matrix pipe (pinn_rnet_mfma.hip): (HE, HG) = (32, 10), split-bf16 operands
 bool rnet_mfma_supported(int HE, int HG);
 hipError_t launch_rnet_mfma_fwd(int act, const float* thE, const float* R, int64_t n, float* E, float* g,
-                                float* Eu, int grid, hipStream_t st);
+                                float* Eu, int grid, TileShares shares, hipStream_t st);
 hipError_t launch_rnet_mfma_bwd(int act, const float* thE, const float* R, const float* Eb, const float* gb,
-                                int64_t n, float* part, int stride, int grid, int64_t tile_split, hipStream_t st);
+                                int64_t n, float* part, int stride, int grid, TileShares shares, hipStream_t st);
 
 // ---- the 16-wide reference trunk on the matrix pipe (pinn_rnet_mfma.hip, k_trunk16): two blocks per CU,
 // 64 points per block and trip

@@ -1247,13 +1247,16 @@ static int grid16(int64_t n, int cap)
     return (int)(b < cap ? b : cap);
 }
 
+static TileShares rnet_shares(const pinn_handle* h, int64_t n, int grid, bool reverse);
+
 // E(R), g(R) for the batch: matrix-pipe kernel for the reference widths, lane = point kernels otherwise
 static int rnet_forward(pinn_handle* h, const float* theta, const float* R, int64_t n, float* Eu,
                         hipStream_t st, hipError_t* e)
 {
     const pinn_arch& a = h->arch;
     if (rnet_mfma_supported(a.HE, a.HG)) {
-        *e = launch_rnet_mfma_fwd(a.act, theta + h->PT, R, n, h->E, h->g, Eu, grid16(n, h->nbR * 2), st);
+        const int gF = grid16(n, h->nbR * 2);
+        *e = launch_rnet_mfma_fwd(a.act, theta + h->PT, R, n, h->E, h->g, Eu, gF, rnet_shares(h, n, gF, false), st);
         return 1;
     }
     return launch_rnet_fwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, n, h->E, h->g, Eu,
@@ -1286,49 +1289,67 @@ static int trunk_grid(const pinn_handle* h, int64_t n, int mode)
     return grid_for(n, h->nbT);
 }
 
-// tiles for the first half of the grid (TrunkArgs::tile_split): an unequal share only when the grid is the full
-// two-blocks-per-CU one, where blocks b and b + grid/2 share a CU.  Shares measured per kernel family on MI355X (round 4,
-// tools/share_sweep.sh, 1M points; +-0.02 off the optimum costs ~1 %): k_trunk2<64> 0.665 (0.426 -> 0.397 ms), k_trunk2s<64>
-// 0.625 (0.265 -> 0.245), k_trunkD<64,4> 0.66 (1.052 -> 0.975), k_trunk16's reverse kernel 0.72 (0.181 -> 0.165: its waves
-// share no barrier, the older block's lead is larger); forward-only sweeps: not measured, equal shares.  PINN_OLDER_SHARE overrides (0.5 = rounds 1-3).
-static int64_t trunk_tile_split(const pinn_handle* h, int64_t n, int grid, int mode)
+// TileShares (pinn_common.h) of a launch.  Unequal shares only for full grids of two or four resident blocks per CU, where
+// blocks b, b + G/K, ... share a CU.  Shares measured per kernel family on MI355X (round 4, tools/share_sweep.sh, 1M points;
+// +-0.02 off the optimum costs ~1 %): k_trunk2<64> 0.665 (0.426 -> 0.397 ms), k_trunk2s<64> 0.625 (0.265 -> 0.245),
+// k_trunkD<64,4> 0.66 (1.052 -> 0.975), k_trunk16's reverse kernel 0.72 (0.181 -> 0.165: its waves share no barrier, the
+// older block's lead is larger), the R-net reverse kernel 0.68.  Four blocks per CU (k_trunk16's forward-only sweeps, the
+// R-net forward kernel): geometric shares 1 : q : q^2 : q^3.  PINN_OLDER_SHARE / PINN_RNET_SHARE / PINN_SHARE_Q override
+// (0.5 / 0.5 / 1.0 = rounds 1-3); read once per process, except under PINN_MFMA_VARIANT_LIVE=1 (tests and tools switch them).
+// defaults of the four-class shares, tools/q_sweep.sh at 1M points: k_trunk16's forward-only sweep 0.0904 ms at q = 1,
+// 0.0861 / 0.0874 / 0.0866 / 0.0854 at 0.65 / 0.5 / 0.4 / 0.3; k_rnet_mfma_fwd 37.1 us at 1, 34.4 / 34.4 / 33.9 / 36.6
+constexpr double kShareQ16 = 0.4, kShareQR = 0.45;
+static double env_share(const char* name, double lo, double hi)
 {
-    auto read = [] {
-        const char* e = getenv("PINN_OLDER_SHARE");
-        const double v = e ? atof(e) : 0.0;
-        return (v >= 0.5 && v <= 0.9) ? v : 0.0;
-    };
-    // read once per process, except under PINN_MFMA_VARIANT_LIVE=1 (the tests and tools switch it inside one process)
+    const char* e = getenv(name);
+    const double v = e ? atof(e) : 0.0;
+    return (v >= lo && v <= hi) ? v : 0.0;
+}
+static bool env_live()
+{
     static const bool live = [] { const char* e = getenv("PINN_MFMA_VARIANT_LIVE"); return e && e[0] == '1'; }();
-    static const double once = read();
-    const double forced = live ? read() : once;
-    if (grid != 2 * h->cus || mode != MODE_BWD) return -1;
+    return live;
+}
+static TileShares shares_two(int64_t n, double share)
+{
+    TileShares ts{};
+    ts.nclass = 2;
+    ts.bound[0] = (int64_t)((double)((n + 15) / 16) * share + 0.5);
+    return ts;
+}
+static TileShares shares_four(int64_t n, double q)
+{
+    TileShares ts{};
+    ts.nclass = 4;
+    const double tot = 1.0 + q + q * q + q * q * q, nt = (double)((n + 15) / 16);
+    ts.bound[0] = (int64_t)(nt / tot + 0.5);
+    ts.bound[1] = (int64_t)(nt * (1.0 + q) / tot + 0.5);
+    ts.bound[2] = (int64_t)(nt * (1.0 + q + q * q) / tot + 0.5);
+    return ts;
+}
+static TileShares trunk_shares(const pinn_handle* h, int64_t n, int grid, int mode)
+{
+    static const double once = env_share("PINN_OLDER_SHARE", 0.5, 0.9), once_q = env_share("PINN_SHARE_Q", 0.05, 1.0);
+    const double forced = env_live() ? env_share("PINN_OLDER_SHARE", 0.5, 0.9) : once;
+    const double forced_q = env_live() ? env_share("PINN_SHARE_Q", 0.05, 1.0) : once_q;
     const pinn_arch& a = h->arch;
-    double share;
-    if (a.precision == PINN_PREC_F32) {
-        if (!trunk16_mfma_supported(a.H, a.L)) return -1;
-        share = 0.72;
-    } else {
-        share = a.L == 4 ? 0.66 : (a.n_pass == 1 ? 0.625 : 0.665);
-    }
+    const bool t16 = a.precision == PINN_PREC_F32 && trunk16_mfma_supported(a.H, a.L);
+    if (grid == 4 * h->cus && t16 && mode != MODE_BWD)            // k_trunk16's forward-only sweeps: four blocks per CU
+        return shares_four(n, forced_q > 0.0 ? forced_q : kShareQ16);
+    if (grid != 2 * h->cus || mode != MODE_BWD || (a.precision == PINN_PREC_F32 && !t16)) return TileShares{};
+    double share = t16 ? 0.72 : (a.L == 4 ? 0.66 : (a.n_pass == 1 ? 0.625 : 0.665));
     if (forced > 0.0) share = forced;
-    const int64_t t16 = (n + 15) / 16;
-    return (int64_t)((double)t16 * share + 0.5);
+    return shares_two(n, share);
 }
 
-// the same for the R-net reverse kernel (two 4-wave blocks per CU): PINN_RNET_SHARE overrides
-static int64_t rnet_tile_split(const pinn_handle* h, int64_t n, int grid)
+// the same for the R-net kernels on the matrix pipe: reverse two blocks per CU, forward four
+static TileShares rnet_shares(const pinn_handle* h, int64_t n, int grid, bool reverse)
 {
-    auto read = [] {
-        const char* e = getenv("PINN_RNET_SHARE");
-        const double v = e ? atof(e) : 0.0;
-        return (v >= 0.5 && v <= 0.9) ? v : 0.68;     // 53.0 -> 50.0 us per 1M points (rocprofv3, tools/rnet_share_sweep.sh)
-    };
-    static const bool live = [] { const char* e = getenv("PINN_MFMA_VARIANT_LIVE"); return e && e[0] == '1'; }();
-    static const double once = read();
-    const double share = live ? read() : once;
-    if (grid != 2 * h->cus) return -1;
-    return (int64_t)((double)((n + 15) / 16) * share + 0.5);
+    static const double once = env_share("PINN_RNET_SHARE", 0.5, 0.9), once_q = env_share("PINN_RNET_Q", 0.05, 1.0);
+    const double forced = env_live() ? env_share("PINN_RNET_SHARE", 0.5, 0.9) : once;
+    const double forced_q = env_live() ? env_share("PINN_RNET_Q", 0.05, 1.0) : once_q;
+    if (reverse) return grid == 2 * h->cus ? shares_two(n, forced > 0.0 ? forced : 0.68) : TileShares{};   // 53.0 -> 50.0 us per 1M points
+    return grid == 4 * h->cus ? shares_four(n, forced_q > 0.0 ? forced_q : kShareQR) : TileShares{};
 }
 
 static int run_trunk(pinn_handle* h, int mode, const float* theta, const TrunkArgs& A, int grid,
@@ -1556,7 +1577,7 @@ extern "C" int pinn_forward(pinn_handle* h, const float* theta, const float* x, 
     A.n = n; A.a = ham->a; A.b = ham->b; A.c = ham->c; A.P = ham->P; A.out_scale = a.out_scale;
     A.invN = 0.f; A.invN1 = 0.f; A.invN2 = 0.f;
     A.psi = psi; A.lap = lap; A.res = res;
-    A.tile_split = -1;
+    A.shares = trunk_shares(h, n, trunk_grid(h, n, MODE_FWD), MODE_FWD);
     if (!run_trunk(h, MODE_FWD, theta, A, trunk_grid(h, n, MODE_FWD), st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no trunk kernel for this (H, L, precision)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_trunk<FWD>", e);
@@ -1590,7 +1611,7 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     A.invN = ham->invN; A.invN1 = ham->invN1; A.invN2 = ham->invN2;
     A.bc_counts = (const long long*)bc_counts;
     A.Eb = h->Eb; A.gb = h->gb; A.partial = h->partT; A.stride = h->strideT;
-    A.tile_split = trunk_tile_split(h, n, gT, trunk_trainable ? MODE_BWD : MODE_HEAD);
+    A.shares = trunk_shares(h, n, gT, trunk_trainable ? MODE_BWD : MODE_HEAD);
 #ifdef PINN_STAMPS
     if (const char* sp = getenv("PINN_STAMP_PTR")) A.psi = (float*)strtoull(sp, nullptr, 16);   // diagnostic build only
 #endif
@@ -1605,7 +1626,7 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     }
     if (rmfma)
         e = launch_rnet_mfma_bwd(a.act, theta + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR,
-                                 rnet_tile_split(h, n, gR), st);
+                                 rnet_shares(h, n, gR, true), st);
     else if (!launch_rnet_bwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_bwd", e);

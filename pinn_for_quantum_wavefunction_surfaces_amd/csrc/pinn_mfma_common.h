@@ -374,28 +374,33 @@ __device__ __forceinline__ void life_write(float*, int, int, unsigned long long,
 #endif
 
 // ------------------------------------------------------------------ which tiles a block takes
-// The grid is two classes of blocks, [0, G0) and [G0, G) with G0 = G / 2; each class stripes its own range of the
-// ntile tiles: block b of a class takes first, first + stride, ... below end.  The first class gets `split` tiles
-// (split < 0: a share proportional to its size, i.e. the plain striping of rounds 1-3 up to the order of the tiles).
-// Why: TrunkArgs::tile_split.  `unit` = points per tile / 16 (split is counted in 16-point tiles).
+// The grid is K classes of G / K consecutive blocks (the last class also takes the G % K left over); each class stripes
+// its own range of the ntile tiles: block b of a class takes first, first + stride, ... below end.  K and the ranges come
+// from TileShares (pinn_common.h: why); nclass = 0 gives two classes with shares proportional to their sizes, i.e. the
+// plain striping of rounds 1-3 up to the order of the tiles.  `unit` = points per tile / 16 (bounds are in 16-point tiles).
 struct BlockTiles {
     int64_t first, end;
     int stride;
     __device__ __forceinline__ int64_t count() const { return end > first ? (end - first + stride - 1) / stride : 0; }
 };
-__device__ __forceinline__ BlockTiles block_tiles(int64_t ntile, int64_t split, int unit = 1)
+__device__ __forceinline__ BlockTiles block_tiles(int64_t ntile, const TileShares& ts, int unit = 1)
 {
-    const int G = (int)gridDim.x, G0 = G >> 1, b = (int)blockIdx.x;
-    const bool c0 = b < G0;
-    int64_t T0 = 0;
-    if (G0) {
-        T0 = split >= 0 ? (split + unit - 1) / unit : ntile * G0 / G;
-        if (T0 > ntile) T0 = ntile;
-    }
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const bool given = ts.nclass == 2 || ts.nclass == 4;
+    const int K = G < 2 ? 1 : (given && G >= ts.nclass ? ts.nclass : 2);
+    const int per = G / K;
+    int c = b / per;
+    if (c >= K) c = K - 1;
+    const int lo_b = c * per, nb = c == K - 1 ? G - lo_b : per;
+    auto upper = [&](int k) -> int64_t {          // upper tile bound of class k
+        if (k >= K - 1) return ntile;
+        int64_t t = given && K == ts.nclass ? (ts.bound[k] + unit - 1) / unit : ntile * ((int64_t)(k + 1) * per) / G;
+        return t > ntile ? ntile : t;
+    };
     BlockTiles t;
-    t.first = c0 ? (int64_t)b : T0 + (b - G0);
-    t.end = c0 ? T0 : ntile;
-    t.stride = c0 ? G0 : G - G0;
+    t.first = (c ? upper(c - 1) : 0) + (b - lo_b);
+    t.end = upper(c);
+    t.stride = nb;
     return t;
 }
 

@@ -161,7 +161,7 @@ template <int ACT>
 __global__ __launch_bounds__(kBlock) void k_rnet_mfma_fwd(const float* __restrict__ thE,
                                                           const float* __restrict__ R, int64_t n,
                                                           float* __restrict__ E, float* __restrict__ gout,
-                                                          float* __restrict__ Eu)
+                                                          float* __restrict__ Eu, TileShares shares)
 {
     constexpr RnetLayout Lo{32, 10};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
@@ -170,10 +170,14 @@ __global__ __launch_bounds__(kBlock) void k_rnet_mfma_fwd(const float* __restric
     bf16x8 Ah[2], Am[2], Al[2];
 #pragma unroll
     for (int jt = 0; jt < 2; jt++) rnet_weight_frag3(thE + Lo.WE2(), jt, g, c, Ah[jt], Am[jt], Al[jt]);
-    const int64_t ntile = (n + 15) / 16, tstep = (int64_t)gridDim.x * kWavesPerBlock;
+    // a block takes kWavesPerBlock consecutive tiles per trip (one per wave); which ones: block_tiles (TileShares)
+    const int64_t ntile0 = (n + 15) / 16;
+    const BlockTiles bt = block_tiles((ntile0 + kWavesPerBlock - 1) / kWavesPerBlock, shares, kWavesPerBlock);
+    const int64_t tstep = (int64_t)bt.stride * kWavesPerBlock;
+    const int64_t ntile = bt.end * kWavesPerBlock < ntile0 ? bt.end * kWavesPerBlock : ntile0;
     // the next trip's R is requested before this trip's arithmetic: one exposed load per wave, not one per tile
     auto clampi = [n](int64_t i) { return i < n ? i : n - 1; };
-    int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    int64_t tile = bt.first * kWavesPerBlock + wave;
     float Rnext = tile < ntile ? R[clampi(tile * 16 + c)] : 0.f;
     for (; tile < ntile; tile += tstep) {
         const int64_t idx = tile * 16 + c;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_rnet_mfma_bwd(const float* __rest
                                                              const float* __restrict__ Eb,
                                                              const float* __restrict__ gb, int64_t n,
                                                              float* __restrict__ partial, int stride,
-                                                             int64_t tile_split)
+                                                             TileShares shares)
 {
     constexpr RnetLayout Lo{32, 10};
     constexpr int PR = Lo.size();
@@ -225,9 +229,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_rnet_mfma_bwd(const float* __rest
         wacc[a][0] = splat(0.f); wacc[a][1] = splat(0.f);
     }
     const float lead = g == 0 ? 1.0f : 0.0f;
-    // a block takes kWavesPerBlock consecutive tiles per trip (one per wave); which ones: block_tiles (TrunkArgs::tile_split)
+    // a block takes kWavesPerBlock consecutive tiles per trip (one per wave); which ones: block_tiles (TileShares)
     const int64_t ntile0 = (n + 15) / 16;
-    const BlockTiles bt = block_tiles((ntile0 + kWavesPerBlock - 1) / kWavesPerBlock, tile_split, kWavesPerBlock);
+    const BlockTiles bt = block_tiles((ntile0 + kWavesPerBlock - 1) / kWavesPerBlock, shares, kWavesPerBlock);
     const int64_t tstep = (int64_t)bt.stride * kWavesPerBlock;
     const int64_t ntile = bt.end * kWavesPerBlock < ntile0 ? bt.end * kWavesPerBlock : ntile0;
     // the next trip's point record (R, E-bar, g-bar) is requested before this trip's arithmetic
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_BWD ? 2 : 4) void k_trunk16(co
     // the point record of the next tile is requested one trip ahead (nothing waits for it until then)
     struct PointRec { float x, y, z, R, E, g; unsigned mk; };
     // a block takes kWavesPerBlock consecutive tiles per trip (one per wave): block_tiles in units of that many tiles
-    const BlockTiles bt = block_tiles((ntile + kWavesPerBlock - 1) / kWavesPerBlock, A.tile_split, kWavesPerBlock);
+    const BlockTiles bt = block_tiles((ntile + kWavesPerBlock - 1) / kWavesPerBlock, A.shares, kWavesPerBlock);
     const int64_t tstep = (int64_t)bt.stride * kWavesPerBlock, tlast = bt.end * kWavesPerBlock < ntile ? bt.end * kWavesPerBlock : ntile;
     auto load_rec = [&](int64_t tl) {
         int64_t id = tl * 16 + c;
@@ -715,22 +719,22 @@ bool rnet_mfma_supported(int HE, int HG)
 }
 
 hipError_t launch_rnet_mfma_fwd(int act, const float* thE, const float* R, int64_t n, float* E, float* g,
-                                float* Eu, int grid, hipStream_t st)
+                                float* Eu, int grid, TileShares shares, hipStream_t st)
 {
     if (act == ACT_SIGMOID)
-        hipLaunchKernelGGL(k_rnet_mfma_fwd<ACT_SIGMOID>, dim3(grid), dim3(kBlock), 0, st, thE, R, n, E, g, Eu);
+        hipLaunchKernelGGL(k_rnet_mfma_fwd<ACT_SIGMOID>, dim3(grid), dim3(kBlock), 0, st, thE, R, n, E, g, Eu, shares);
     else
-        hipLaunchKernelGGL(k_rnet_mfma_fwd<ACT_TANH>, dim3(grid), dim3(kBlock), 0, st, thE, R, n, E, g, Eu);
+        hipLaunchKernelGGL(k_rnet_mfma_fwd<ACT_TANH>, dim3(grid), dim3(kBlock), 0, st, thE, R, n, E, g, Eu, shares);
     return hipGetLastError();
 }
 
 hipError_t launch_rnet_mfma_bwd(int act, const float* thE, const float* R, const float* Eb, const float* gb,
-                                int64_t n, float* part, int stride, int grid, int64_t tile_split, hipStream_t st)
+                                int64_t n, float* part, int stride, int grid, TileShares shares, hipStream_t st)
 {
     if (act == ACT_SIGMOID)
-        hipLaunchKernelGGL(k_rnet_mfma_bwd<ACT_SIGMOID>, dim3(grid), dim3(kBlock), 0, st, thE, R, Eb, gb, n, part, stride, tile_split);
+        hipLaunchKernelGGL(k_rnet_mfma_bwd<ACT_SIGMOID>, dim3(grid), dim3(kBlock), 0, st, thE, R, Eb, gb, n, part, stride, shares);
     else
-        hipLaunchKernelGGL(k_rnet_mfma_bwd<ACT_TANH>, dim3(grid), dim3(kBlock), 0, st, thE, R, Eb, gb, n, part, stride, tile_split);
+        hipLaunchKernelGGL(k_rnet_mfma_bwd<ACT_TANH>, dim3(grid), dim3(kBlock), 0, st, thE, R, Eb, gb, n, part, stride, shares);
     return hipGetLastError();
 }
 

@@ -56,6 +56,7 @@ template <int H, int L, int ACT, int VAR = 0>
 __global__ __launch_bounds__((TDCfg<H, L>::WAVES * 64), (TDCfg<H, L>::OCC * TDCfg<H, L>::WAVES / 4))
 void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, uint4* __restrict__ stash_g, TrunkArgs A)
 {
+    const unsigned long long life0 = PINN_LIFE_NOW();
     constexpr bool SWZ = (VAR & 1) == 0;
     using C = TDCfg<H, L>;
     using Lay = TrunkLayout<H, L>;
@@ -143,7 +144,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     }
     const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
-    const BlockTiles bt = block_tiles(ntile, A.tile_split);      // this block's tiles: first, first + stride, ... < end
+    const BlockTiles bt = block_tiles(ntile, A.shares);      // this block's tiles: first, first + stride, ... < end
     const int64_t tfirst = bt.first, tend = bt.end, iters = bt.count();
     const int tstride = bt.stride;
 
@@ -252,6 +253,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
 #else
 #define TD_STAMP(i) do { } while (0)
 #endif
+    const unsigned long long life1 = PINN_LIFE_NOW();
     for (int64_t itx = 0; itx < iters; itx++) {
         const int64_t tile = tfirst + itx * tstride;
         const int64_t idx = tile * 16 + c;
@@ -493,6 +495,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     }
 #endif
 #undef TD_STAMP
+    const unsigned long long life2 = PINN_LIFE_NOW();
     // =========================== block reduction ===========================
     __syncthreads();
     constexpr int PT = Lay::size;
@@ -536,6 +539,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     }
     if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
     if (threadIdx.x == 3) out[Lay::bout] = sc[3];
+    life_write(A.psi, C::WAVES, part, life0, life1, life2);
 }
 
 template <int H, int L, int ACT, int VAR = 0>
@@ -597,6 +601,7 @@ template <int ACT, int VAR = 0>
 __global__ __launch_bounds__(TDxCfg::WAVES * 64, 2)
 void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g, uint4* __restrict__ stash_g, TrunkArgs A)
 {
+    const unsigned long long life0 = PINN_LIFE_NOW();
     using C = TDxCfg;
     constexpr bool SWZ = (VAR & 1) != 0, PIPE = (VAR & 2) == 0;
     constexpr int H = C::H, L = C::L, HT = C::HT, KC = C::KC, NT = C::WAVES * 64, EB = C::EB, EB1 = C::EB1, NW = C::NW;
@@ -849,6 +854,7 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
 #else
 #define TDX_STAMP(i) do { } while (0)
 #endif
+    const unsigned long long life1 = PINN_LIFE_NOW();
     for (int64_t itx = 0; itx < iters; itx++) {
         const int64_t tile = itx * gridDim.x + blockIdx.x;
         const int64_t idx = tile * 16 + c;
@@ -1047,6 +1053,7 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     }
 #endif
 #undef TDX_STAMP
+    const unsigned long long life2 = PINN_LIFE_NOW();
     // =========================== block reduction ===========================
     __syncthreads();
     constexpr int PT = Lay::size;
@@ -1089,6 +1096,7 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     }
     if (threadIdx.x < 3) out[PT + threadIdx.x] = sc[threadIdx.x];
     if (threadIdx.x == 3) out[Lay::bout] = sc[3];
+    life_write(A.psi, C::WAVES, part, life0, life1, life2);
 }
 
 template <int ACT, int VAR = 0>

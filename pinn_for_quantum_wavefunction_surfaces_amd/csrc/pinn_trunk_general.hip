@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WAVES * 64, (OCC > 1 ? OCC : 1) * WAVES / 4) void k
     const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
     // a block takes GROUPS consecutive tiles per trip (one per group): block_tiles in units of GROUPS tiles
-    const BlockTiles bt = block_tiles((ntile + C::GROUPS - 1) / C::GROUPS, A.tile_split, C::GROUPS);
+    const BlockTiles bt = block_tiles((ntile + C::GROUPS - 1) / C::GROUPS, A.shares, C::GROUPS);
     const int64_t iters = bt.count();   // same for every wave of the block: barriers match
 
     // the point record of the NEXT tile is requested one trip ahead (7 loads per lane that nothing waits

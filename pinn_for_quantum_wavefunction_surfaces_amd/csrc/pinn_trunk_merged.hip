@@ -116,7 +116,7 @@ void k_trunk2(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     }
     const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
-    const BlockTiles bt = block_tiles(ntile, A.tile_split);      // this block's tiles: first, first + stride, ... < end
+    const BlockTiles bt = block_tiles(ntile, A.shares);      // this block's tiles: first, first + stride, ... < end
     const int64_t tfirst = bt.first, tend = bt.end, iters = bt.count();
     const int tstride = bt.stride;
 
@@ -523,7 +523,7 @@ void k_trunk2s(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     }
     const float lead = (g == 0 && part == 0) ? 1.0f : 0.0f;
     const int64_t ntile = (A.n + 15) / 16;
-    const BlockTiles bt = block_tiles(ntile, A.tile_split);      // this block's tiles: first, first + stride, ... < end
+    const BlockTiles bt = block_tiles(ntile, A.shares);      // this block's tiles: first, first + stride, ... < end
     const int64_t tfirst = bt.first, tend = bt.end, iters = (bt.count() + NTL - 1) / NTL;   // NTL tiles per trip
     const int tstride = bt.stride;
 

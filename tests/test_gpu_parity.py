@@ -971,7 +971,8 @@ def test_bitwise_reproducible_with_co_resident_blocks(H, L, prec):
 @pytest.mark.parametrize("H,L,prec", [(16, 2, "f32"), (64, 2, "bf16"), (64, 2, "bf16-B"), (64, 4, "bf16"), (128, 2, "bf16")])
 def test_unequal_tile_shares_only_reorder_the_sums(H, L, prec, monkeypatch):
     """Round 4: at a full two-blocks-per-CU grid the first half of the blocks (the ones that reach a CU first and win its
-    issue arbitration) takes a larger share of the tiles (TrunkArgs::tile_split, PINN_OLDER_SHARE / PINN_RNET_SHARE).  The
+    issue arbitration) takes a larger share of the tiles (TileShares in csrc/pinn_common.h; PINN_OLDER_SHARE / PINN_RNET_SHARE,
+    and PINN_SHARE_Q / PINN_RNET_Q for the kernels with four blocks per CU: the R-net forward kernel here).  The
     share must move tiles between blocks and nothing else: every share -- equal, the default, an extreme one -- gives the
     same losses and gradient up to the order of the fp32 block sums, on a ragged batch (one dropped or doubled tile of
     the 8 193 would move a loss by 1.2e-4).  (H = 128: one block per CU, the share is not used -- same check.)"""
@@ -994,11 +995,13 @@ def test_unequal_tile_shares_only_reorder_the_sums(H, L, prec, monkeypatch):
     P = O.param_count(A)
     out = {}
     for share in ("0.5", None, "0.85"):
-        for var in ("PINN_OLDER_SHARE", "PINN_RNET_SHARE"):
-            if share is None:
+        for var, val in (("PINN_OLDER_SHARE", share), ("PINN_RNET_SHARE", share),
+                         ("PINN_SHARE_Q", {"0.5": "1.0", "0.85": "0.15"}.get(share)),
+                         ("PINN_RNET_Q", {"0.5": "1.0", "0.85": "0.15"}.get(share))):
+            if val is None:
                 monkeypatch.delenv(var, raising=False)
             else:
-                monkeypatch.setenv(var, share)
+                monkeypatch.setenv(var, val)
         out[share] = run_loss_grad(h, f, theta, x, y, z, R, mask).astype(np.float64)
         assert np.isfinite(out[share]).all()
     ref = out["0.5"]
@@ -1006,6 +1009,38 @@ def test_unequal_tile_shares_only_reorder_the_sums(H, L, prec, monkeypatch):
         for k in range(3):
             assert abs(out[share][P + k] / ref[P + k] - 1) < 2e-5, (share, k)
         assert rel(out[share][:P], ref[:P]) < 2e-5, share
+
+
+def test_four_class_tile_shares_only_reorder_the_sums(golden_dir, monkeypatch):
+    """The kernels with FOUR resident blocks per CU (k_trunk16's forward-only sweeps: fine-tune and pinn_forward; the R-net
+    forward kernel) give the four arrival classes geometric shares 1 : q : q^2 : q^3 at a full grid (PINN_SHARE_Q, PINN_RNET_Q).
+    Equal shares, the defaults and an extreme ratio: psi, E, the Laplacian and the residual of every point are the same bits
+    (no sums involved), and the fine-tune gradient agrees up to the order of the block sums -- on a ragged batch."""
+    g = np.load(os.path.join(golden_dir, "g2_formA_fineTune.npz"))
+    arch, f = make()
+    n = 131072 + 7
+    rng = np.random.default_rng(4)
+    x, y, z = rng.uniform(-18, 18, (3, n))
+    R = rng.uniform(0.2, 3, n)
+    mask = rng.integers(0, 4, n).astype(np.uint8)
+    h = capi.Handle(arch, 0, n)
+    tmask = sum(1 << t for t in range(6, 12))
+    fwd, grad = {}, {}
+    for q in ("1.0", None, "0.15"):
+        for var in ("PINN_SHARE_Q", "PINN_RNET_Q"):
+            if q is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, q)
+        fwd[q] = run_forward(h, f, g["theta"], x, y, z, R)
+        grad[q] = run_loss_grad(h, f, g["theta"], x, y, z, R, mask, tmask)
+    for q in (None, "0.15"):
+        for a, b in zip(fwd[q], fwd["1.0"]):
+            assert np.array_equal(a, b)
+        assert np.isfinite(grad[q]).all()
+        for k in range(3):
+            assert abs(grad[q][h.P + k] / grad["1.0"][h.P + k] - 1) < 2e-5
+        assert rel(grad[q][:h.P], grad["1.0"][:h.P]) < 2e-5
 
 
 @pytest.mark.parametrize("H,L,form,act", [(64, 2, "B", 1), (128, 2, "A", 0), (128, 2, "B", 1),

@@ -32,6 +32,9 @@ def main():
     params = pkg.set_params()
     torch.manual_seed(12345)
     m = pkg.NN_ion(params, a["H"], a["HE"], a["HG"], n_hidden=a["L"], act=a["act_name"], precision=a["precision"]).to(dev)
+    if a.get("fine_tune"):
+        m.freezeDecayUnit()
+        m.freezeBase()
     tr = pkg.Trainer(m, params, n_points=args.points, lr=8e-3, seed=12345, device=dev)
     waves = max(a["H"] // 16, 4)                 # waves per block of the trunk kernel (k_trunk16: 4)
     OFF = 4096 * 8 * 8                           # life records sit behind the phase-stamp region (csrc/pinn_mfma_common.h)
@@ -68,6 +71,12 @@ def main():
     for b in range(blocks.max() + 1):
         m = blocks == b
         done.setdefault(int(cu[m][0]), []).append((float(us[m, 2].max()), float(us[m, 0].min()), b))
+    sizes = sorted(set(len(v) for v in done.values()))
+    print("  blocks per CU: %s" % sizes)
+    if sizes and sizes[-1] > 2:
+        k = sizes[-1]
+        rows = np.array([[t[0] for t in sorted(v, key=lambda t: t[1])] for v in done.values() if len(v) == k])
+        print("  tiles done after (us), blocks of a CU in the order they entered: " + "  ".join("%.1f" % x for x in np.median(rows, axis=0)))
     pairs = [sorted(v) for v in done.values() if len(v) == 2]
     if pairs:
         first = np.array([p[0][0] for p in pairs]); second = np.array([p[1][0] for p in pairs])
@@ -76,6 +85,16 @@ def main():
         early = np.array([p[0][1] < p[1][1] for p in pairs])
         print("  the first finisher is the block that ENTERED first on %d of %d CUs; block-index distance of the partners: %s" % (
             early.sum(), len(pairs), sorted(set(abs(p[0][2] - p[1][2]) for p in pairs))[:8]))
+    # per XCD (XCC_ID) and per shader engine: is a part of the chip consistently slower?
+    xid = (xcc & 15)
+    bdone = np.array([us[blocks == b, 2].max() for b in range(blocks.max() + 1)])
+    bx = np.array([int(xid[blocks == b][0]) for b in range(blocks.max() + 1)])
+    bse = np.array([int(((hw >> 13) & 7)[blocks == b][0]) for b in range(blocks.max() + 1)])
+    bcu = np.array([int(((hw >> 8) & 15)[blocks == b][0]) for b in range(blocks.max() + 1)])
+    print("  last tile done by XCD (median us; blockIdx %% 8 of its blocks): " + "  ".join(
+        "%d: %.0f %s" % (x, np.median(bdone[bx == x]), sorted(set((np.nonzero(bx == x)[0] % 8).tolist()))) for x in sorted(set(bx.tolist()))))
+    print("  by shader engine: " + "  ".join("%d: %.0f" % (e, np.median(bdone[bse == e])) for e in sorted(set(bse.tolist()))))
+    print("  by CU id within its engine: " + "  ".join("%d: %.0f" % (c, np.median(bdone[bcu == c])) for c in sorted(set(bcu.tolist()))))
     h, edges = np.histogram(us[:, 2], bins=12)
     print("  histogram of 'last tile done' (us): " + "  ".join("%.0f-%.0f:%d" % (edges[i], edges[i + 1], h[i]) for i in range(len(h))))
 

@@ -29,6 +29,11 @@ namespace {
 //     instead of being saved.
 // Barriers per tile: 1 (layer 0) + (L-1) forward + 1 (tail) + per reverse step one after the GEMMs (the adjoint
 // buffer is overwritten by the next layer's adjoints) and one after those are written.
+#ifdef PINN_STASH_PAD
+constexpr int kStashPad = PINN_STASH_PAD;      // (tools/build_flags.py: experiments)
+#else
+constexpr int kStashPad = 4096;
+#endif
 template <int H, int L>
 struct TDCfg {
     static constexpr int HT = H / 16, KC = H / 32, WAVES = H / 16, NW = L - 1;
@@ -44,7 +49,15 @@ struct TDCfg {
     static constexpr size_t OFF_S = OFF_SMALL + NSMALL * 4;
     static constexpr size_t OFF_R = OFF_S + WAVES * 16 * 2 * 4;
     static constexpr size_t LDS_BYTES = OFF_R + RBYTES;
-    static constexpr size_t STASH_BLOCK = STASH ? (size_t)(NW - 1) * WAVES * 4 * 1024 : 0;   // bytes per block
+    // Parked-state slot of a block: [layer][wave][4 KB], slots kStashPad bytes apart beyond their size.  With slots at a
+    // power-of-two stride (64 KB, rounds 2-4) the L2 kept missing on the parked state (FETCH_SIZE 1.84 GB per 1M points of
+    // the 4 GB loaded) and the blocks whose slot address has bit 17 ^ bit 22 ^ bit 23 set finished 6.5 % after the others,
+    // whatever CU they ran on (tools/lifecycle.py --save: per-block times correlate 0.99 between runs); 4 KB of padding per
+    // slot: FETCH_SIZE 0.43 GB, kernel 3.75 -> 3.60 ms (steady A/B, tools/ab_libs.sh; 1 / 2 / 8 / 12 / 20 / 36 KB: 3.66 /
+    // 3.44 / 3.46 / 3.60 / 3.61 / 3.53 on the box where 4 KB gave 3.43; pieces interleaved over all blocks: FETCH 0.16 GB,
+    // 3.65 ms).  Every store still reaches the memory side (WRITE_SIZE 3.4-4.0 GB either way).
+    static constexpr int STASH_LAYER = WAVES * 4 * 1024;                                           // bytes per layer of a block
+    static constexpr size_t STASH_BLOCK = STASH ? (size_t)(NW - 1) * STASH_LAYER + kStashPad : 0;  // bytes from slot to slot
     static_assert(OCC * LDS_BYTES <= 160 * 1024, "k_trunkD does not fit the CU's LDS");
     static_assert(OFF_S % 16 == 0 && OFF_R % 16 == 0, "alignment");
 };
@@ -120,12 +133,14 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     };
     // parked saved state of layer l (1..L-2): 8 x u32x2 = 4 x 16 bytes per lane, [k][lane] per wave
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(stash_g, 0, STASH ? (int)(C::STASH_BLOCK * gridDim.x) : 0, 0x00020000);
-    const int ssoff = (blockIdx.x * (NW - 1) * C::WAVES + part) * 4096;
+    // slot of this block: [layer][wave][4 KB], slots STASH_BLOCK bytes apart (see TDCfg)
+    const int ssoff = (int)(blockIdx.x * C::STASH_BLOCK) + part * 4096;
+    auto stash_so = [&](int l) { return ssoff + (l - 1) * C::STASH_LAYER; };
     auto stash_put = [&](int l, int k, u32x4 v) {
-        __builtin_amdgcn_raw_buffer_store_b128(v, srs, lane16 + k * 1024, ssoff + (l - 1) * C::WAVES * 4096, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, srs, lane16 + k * 1024, stash_so(l), 0);
     };
     auto stash_get = [&](int l, int k) {
-        return __builtin_amdgcn_raw_buffer_load_b128(srs, lane16 + k * 1024, ssoff + (l - 1) * C::WAVES * 4096, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(srs, lane16 + k * 1024, stash_so(l), 0);
     };
 
     f32x4 wacc[NW][HT], bacc[L], w0acc0 = splat(0.f), w0acc1 = splat(0.f), woacc = splat(0.f);
@@ -590,7 +605,7 @@ struct TDxCfg {
     static constexpr size_t OFF_S = OFF_SMALL + NSMALL * 4;       // [wave][16 points][pass][Sv, Sl]
     static constexpr size_t OFF_R = OFF_S + WAVES * 16 * 2 * 2 * 4;
     static constexpr size_t LDS_BYTES = OFF_R + RBYTES;
-    static constexpr size_t STASH_BLOCK = (size_t)(NW - 1) * WAVES * 4 * 1024;   // bytes per block (one pass at a time)
+    static constexpr size_t STASH_BLOCK = (size_t)(NW - 1) * WAVES * 4 * 1024 + kStashPad;   // bytes from slot to slot (one pass at a time; padding: TDCfg)
     static_assert(LDS_BYTES <= 160 * 1024, "k_trunkDx does not fit the CU's LDS");
     static_assert(OFF_S % 16 == 0 && OFF_R % 16 == 0, "alignment");
 };
@@ -652,7 +667,7 @@ void k_trunkDx(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wpk_g), 0, 2 * WPLANE_B, 0x00020000);
     const int wsoff = part * KC * 1024;         // the wave's part of the buffer offsets is uniform: scalar offset
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(stash_g, 0, (int)(C::STASH_BLOCK * gridDim.x), 0x00020000);
-    const int ssoff = (blockIdx.x * (NW - 1) * C::WAVES + part) * 4096;
+    const int ssoff = (int)(blockIdx.x * C::STASH_BLOCK) + part * 4096;
     auto stash_put = [&](int l, int k, f32x4 v) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srs, sw16 + k * 1024, ssoff + (l - 1) * C::WAVES * 4096, 0);
     };

@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=4000)
     ap.add_argument("--arch", default="wide64")
+    ap.add_argument("--save", default="", help="write per-block records (block, xcc, se, sh, cu, entry, done) to this .npy")
     args = ap.parse_args()
     os.environ["PINN_HIP_LIB"] = os.path.join(PKG, "libpinn_hip_stamps.so")
     sys.path.insert(0, ROOT)
@@ -95,6 +96,10 @@ def main():
         "%d: %.0f %s" % (x, np.median(bdone[bx == x]), sorted(set((np.nonzero(bx == x)[0] % 8).tolist()))) for x in sorted(set(bx.tolist()))))
     print("  by shader engine: " + "  ".join("%d: %.0f" % (e, np.median(bdone[bse == e])) for e in sorted(set(bse.tolist()))))
     print("  by CU id within its engine: " + "  ".join("%d: %.0f" % (c, np.median(bdone[bcu == c])) for c in sorted(set(bcu.tolist()))))
+    if args.save:
+        ben = np.array([us[blocks == b, 0].min() for b in range(blocks.max() + 1)])
+        bsh = np.array([int(((hw >> 12) & 1)[blocks == b][0]) for b in range(blocks.max() + 1)])
+        np.save(args.save, np.stack([np.arange(len(bdone)), bx, bse, bsh, bcu, ben, bdone], 1))
     h, edges = np.histogram(us[:, 2], bins=12)
     print("  histogram of 'last tile done' (us): " + "  ".join("%.0f-%.0f:%d" % (edges[i], edges[i + 1], h[i]) for i in range(len(h))))
 

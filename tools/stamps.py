@@ -16,18 +16,23 @@ PKG = os.path.join(ROOT, "pinn_for_quantum_wavefunction_surfaces_amd")
 SO = os.path.join(PKG, "libpinn_hip_stamps.so")
 
 
-def build():
+def build(flags=("-DPINN_STAMPS",), out=SO, tag="stamps"):
+    """every translation unit with extra flags into another .so (the diagnostic build; tools/build_flags.py: experiments)"""
     sys.path.insert(0, ROOT)
     from pinn_for_quantum_wavefunction_surfaces_amd.build import UNITS
-    objs = []
+    objs, procs = [], []
+    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
     for objname, src, extra in UNITS:
-        o = os.path.join(PKG, "build", objname.replace(".o", ".stamps.o"))
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
-                               "-Wno-unused-value", "-DPINN_STAMPS"] + extra + ["-c", "-o", o, src],
-                              cwd=os.path.join(PKG, "csrc"))
+        o = os.path.join(PKG, "build", objname.replace(".o", ".%s.o" % tag))
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
+                                       "-Wno-unused-value"] + list(flags) + extra + ["-c", "-o", o, src],
+                                      cwd=os.path.join(PKG, "csrc")))
         objs.append(o)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
-    print(SO)
+    for pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    print(out)
 
 
 def main():

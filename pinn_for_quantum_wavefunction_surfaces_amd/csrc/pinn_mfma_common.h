@@ -361,7 +361,7 @@ __device__ __forceinline__ void life_write(float* psi, int waves, int wave, unsi
                                            unsigned long long t2)
 {
     if (!psi || (threadIdx.x & 63) != 0) return;
-    unsigned long long* lf = reinterpret_cast<unsigned long long*>(psi) + (size_t)4096 * 8 * 8
+    unsigned long long* lf = reinterpret_cast<unsigned long long*>(psi) + (size_t)4096 * 8 * 32
                              + ((size_t)blockIdx.x * waves + wave) * 6;
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

@@ -38,7 +38,7 @@ def main():
         m.freezeBase()
     tr = pkg.Trainer(m, params, n_points=args.points, lr=8e-3, seed=12345, device=dev)
     waves = max(a["H"] // 16, 4)                 # waves per block of the trunk kernel (k_trunk16: 4)
-    OFF = 4096 * 8 * 8                           # life records sit behind the phase-stamp region (csrc/pinn_mfma_common.h)
+    OFF = 4096 * 8 * 32                           # life records sit behind the phase-stamp region (csrc/pinn_mfma_common.h)
     dbg = torch.zeros(OFF + 4096 * 8 * 6, device=dev, dtype=torch.int64)
     for _ in range(50):
         tr.step()

@@ -62,7 +62,7 @@ def main():
     waves = a["H"] // 16
     deep = a["L"] == 4                     # k_trunkD: 24 slots per wave, k_trunk2: 8
     NS = 24 if deep else 8
-    dbg = torch.zeros(4096 * waves * NS, device=dev, dtype=torch.int64)
+    dbg = torch.zeros(4096 * 8 * 32 + 4096 * 8 * 6, device=dev, dtype=torch.int64)   # phase stamps, then the life records (tools/lifecycle.py)
     for _ in range(50):
         tr.step()
     torch.cuda.synchronize()
@@ -72,7 +72,7 @@ def main():
         tr.step()
     torch.cuda.synchronize()
     ms = tr.h.profile_read(4)
-    d = dbg.cpu().numpy().reshape(-1, NS)
+    d = dbg.cpu().numpy()[:4096 * waves * NS].reshape(-1, NS)
     d = d[d.sum(1) > 0].astype(np.float64)
     if deep and a["precision"] != "bf16":
         return report_deep_x3(args, a, d, ms, waves)

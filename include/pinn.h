@@ -212,6 +212,14 @@ int pinn_xchg_status(pinn_xchg *x, void *stream);
 int pinn_xchg_destroy(pinn_xchg *x);
 const char *pinn_xchg_last_error(const pinn_xchg *x);
 
+/* ---- diagnostics (host only, no GPU call) -------------------------------------------------
+ * The tile -> block map of the trunk kernels (csrc/pinn_common.h block_tiles_of): block b of a grid of `grid` blocks takes
+ * the tiles out[0], out[0] + out[2], ... below out[1].  nclass = 0 (equal shares), 2 or 4 with bounds[nclass - 1] upper
+ * tile bounds in 16-point tiles; unit = points per tile / 16.  For the CPU test that checks that every tile is taken
+ * exactly once whatever the shares. */
+int pinn_debug_block_tiles(int grid, int block, int64_t ntile, int nclass, const int64_t *bounds, int unit,
+                           int64_t out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ PINN_PREC_F32, PINN_PREC_BF16, PINN_PREC_BF16X3 = 0, 1, 2
 EXPORTS = ["pinn_param_count", "pinn_tensor_count", "pinn_tensor_layout", "pinn_strerror",
            "pinn_create", "pinn_destroy", "pinn_last_error", "pinn_sample", "pinn_forward",
            "pinn_residual_fwd_bwd", "pinn_adam", "pinn_sample_dp", "pinn_adam_dp", "pinn_profile_enable", "pinn_profile_read",
+           "pinn_debug_block_tiles",
            "pinn_energy_R", "pinn_quadrature3d", "pinn_xchg_create", "pinn_xchg_local_handle", "pinn_xchg_connect",
            "pinn_xchg_allreduce", "pinn_xchg_set_timeout", "pinn_xchg_status", "pinn_xchg_destroy", "pinn_xchg_last_error"]
 

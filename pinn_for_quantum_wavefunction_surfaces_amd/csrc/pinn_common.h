@@ -22,6 +22,43 @@ struct TileShares {
     int64_t bound[3];         // upper tile bounds of classes 0 .. nclass-2, in 16-point tiles
 };
 
+// tiles of block b of a grid of G: first, first + stride, ... below end.  The grid is K classes of G / K consecutive blocks
+// (the last class also takes the G % K left over); nclass = 0 gives two classes with shares proportional to their sizes,
+// i.e. the plain striping of rounds 1-3 up to the order of the tiles.  `unit` = points per tile / 16 (the bounds of
+// TileShares are in 16-point tiles).  Host and device (the CPU test drives it through pinn_debug_block_tiles).
+struct BlockTiles {
+    int64_t first, end;
+    int stride;
+    __host__ __device__ int64_t count() const { return end > first ? (end - first + stride - 1) / stride : 0; }
+};
+__host__ __device__ inline BlockTiles block_tiles_of(int G, int b, int64_t ntile, const TileShares& ts, int unit)
+{
+    const bool given = ts.nclass == 2 || ts.nclass == 4;
+    const int K = G < 2 ? 1 : (given && G >= ts.nclass ? ts.nclass : 2);
+    const int per = G / K;
+    int c = b / per;
+    if (c >= K) c = K - 1;
+    const int lo_b = c * per, nb = c == K - 1 ? G - lo_b : per;
+    auto raw = [&](int k) -> int64_t {            // upper tile bound of class k as given
+        if (k >= K - 1) return ntile;
+        int64_t t = given && K == ts.nclass ? (ts.bound[k] + unit - 1) / unit : ntile * ((int64_t)(k + 1) * per) / G;
+        if (t < 0) t = 0;
+        return t > ntile ? ntile : t;
+    };
+    // bounds out of order never make ranges overlap: the bound of a class is at least that of the class before it
+    int64_t lo = 0, hi = 0;
+    for (int k = 0; k <= c; k++) {
+        lo = hi;
+        const int64_t r = raw(k);
+        hi = r > hi ? r : hi;
+    }
+    BlockTiles t;
+    t.first = lo + (b - lo_b);
+    t.end = hi;
+    t.stride = nb;
+    return t;
+}
+
 struct TrunkArgs {
     const float *x, *y, *z, *R;
     const float *E, *g;       // from k_rnet_fwd

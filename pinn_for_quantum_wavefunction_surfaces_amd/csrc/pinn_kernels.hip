@@ -1108,6 +1108,18 @@ extern "C" int pinn_tensor_layout(const pinn_arch* a, int64_t* off, int64_t* sz)
     return PINN_OK;
 }
 
+extern "C" int pinn_debug_block_tiles(int grid, int block, int64_t ntile, int nclass, const int64_t* bounds, int unit,
+                                      int64_t out[3])
+{
+    if (grid < 1 || block < 0 || block >= grid || ntile < 0 || unit < 1 || !out) return PINN_ERR_ARG;
+    TileShares ts{};
+    ts.nclass = nclass;
+    for (int k = 0; k < 3 && k < nclass - 1 && bounds; k++) ts.bound[k] = bounds[k];
+    const BlockTiles t = block_tiles_of(grid, block, ntile, ts, unit);
+    out[0] = t.first; out[1] = t.end; out[2] = t.stride;
+    return PINN_OK;
+}
+
 extern "C" const char* pinn_strerror(int s)
 {
     switch (s) {

@@ -378,30 +378,9 @@ __device__ __forceinline__ void life_write(float*, int, int, unsigned long long,
 // its own range of the ntile tiles: block b of a class takes first, first + stride, ... below end.  K and the ranges come
 // from TileShares (pinn_common.h: why); nclass = 0 gives two classes with shares proportional to their sizes, i.e. the
 // plain striping of rounds 1-3 up to the order of the tiles.  `unit` = points per tile / 16 (bounds are in 16-point tiles).
-struct BlockTiles {
-    int64_t first, end;
-    int stride;
-    __device__ __forceinline__ int64_t count() const { return end > first ? (end - first + stride - 1) / stride : 0; }
-};
 __device__ __forceinline__ BlockTiles block_tiles(int64_t ntile, const TileShares& ts, int unit = 1)
 {
-    const int G = (int)gridDim.x, b = (int)blockIdx.x;
-    const bool given = ts.nclass == 2 || ts.nclass == 4;
-    const int K = G < 2 ? 1 : (given && G >= ts.nclass ? ts.nclass : 2);
-    const int per = G / K;
-    int c = b / per;
-    if (c >= K) c = K - 1;
-    const int lo_b = c * per, nb = c == K - 1 ? G - lo_b : per;
-    auto upper = [&](int k) -> int64_t {          // upper tile bound of class k
-        if (k >= K - 1) return ntile;
-        int64_t t = given && K == ts.nclass ? (ts.bound[k] + unit - 1) / unit : ntile * ((int64_t)(k + 1) * per) / G;
-        return t > ntile ? ntile : t;
-    };
-    BlockTiles t;
-    t.first = (c ? upper(c - 1) : 0) + (b - lo_b);
-    t.end = upper(c);
-    t.stride = nb;
-    return t;
+    return block_tiles_of((int)gridDim.x, (int)blockIdx.x, ntile, ts, unit);
 }
 
 }  // namespace

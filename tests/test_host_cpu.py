@@ -254,3 +254,37 @@ def test_profile_summary_keys_and_the_traffic_file_bench_reads():
         assert arch in bench.ARCHS and k in t["bytes_per_launch"], (arch, k)
         assert bench.TRAFFIC[arch] == t["bytes_per_launch"][k] > 1e6
     assert "FETCH_SIZE" in bench.TRAFFIC_SOURCE
+
+
+def test_every_tile_is_taken_exactly_once_whatever_the_shares():
+    """The tile -> block map of the trunk kernels (csrc/pinn_common.h block_tiles_of, driven on the host through
+    pinn_debug_block_tiles): for any grid, tile count, tile unit and TileShares -- equal, two or four classes, bounds beyond the
+    end, out of order, grids smaller than the class count -- the blocks' tile sets partition [0, ntile)."""
+    import ctypes as C
+    lib = capi.load_library()
+    lib.pinn_debug_block_tiles.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.c_int,
+                                           C.POINTER(C.c_int64)]
+    lib.pinn_debug_block_tiles.restype = C.c_int
+    rng = np.random.default_rng(0)
+    cases = [(512, 62500, 2, [41563], 1), (512, 62500, 0, [], 1), (1024, 15625, 4, [9000, 12500, 14000], 4),
+             (1, 7, 2, [3], 1), (2, 0, 2, [0], 1), (3, 10, 4, [2, 4, 6], 1), (5, 100, 4, [50, 75, 90], 1),
+             (512, 8193, 2, [10 ** 9], 1), (512, 8193, 2, [0], 1), (8, 1000, 4, [900, 100, 500], 2), (7, 3, 2, [2], 1)]
+    for _ in range(200):
+        G = int(rng.integers(1, 1100))
+        nt = int(rng.integers(0, 5000))
+        K = int(rng.choice([0, 2, 4]))
+        unit = int(rng.choice([1, 2, 4]))
+        b = sorted(int(v) for v in rng.integers(0, max(nt * unit, 1) + 5, max(K - 1, 0)))
+        cases.append((G, nt, K, b, unit))
+    out = (C.c_int64 * 3)()
+    for G, nt, K, bounds, unit in cases:
+        arr = (C.c_int64 * 3)(*(list(bounds) + [0, 0, 0])[:3])
+        seen = np.zeros(nt, np.int32)
+        for blk in range(G):
+            assert lib.pinn_debug_block_tiles(G, blk, nt, K, arr, unit, out) == 0
+            first, end, stride = out[0], out[1], out[2]
+            assert stride >= 1 and 0 <= end <= nt and first >= 0
+            if end > first:
+                seen[first:end:stride] += 1
+        assert (seen == 1).all(), (G, nt, K, bounds, unit, int((seen != 1).sum()))
+

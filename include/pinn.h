@@ -140,7 +140,7 @@ int pinn_quadrature3d(pinn_handle *h, const float *u, const float *v, const doub
 
 /* Replaces LossFunctions + Ltot.backward() (poc/main.py:341-355,403;
  * train.py:41-57,71): one fused pass computing the loss terms and d(Ltot)/d(theta).
- * out (P+3 floats): gradient, then invN*sum res^2, invN1*sum_{bc1} psi^2,
+ * out (P+3 floats; NULL: leave the per-block partial sums in the handle for pinn_adam_fused): gradient, then invN*sum res^2, invN1*sum_{bc1} psi^2,
  * invN2*sum_{bc2} psi^2 (so Ltot = out[P]+out[P+1]+out[P+2]).  mask as written
  * by pinn_sample (NULL = no boundary points).  Tensors whose trainable_mask bit
  * is 0 get a zero gradient (freezeBase/freezeDecayUnit, poc/main.py:305-319);
@@ -166,6 +166,15 @@ int pinn_residual_fwd_bwd(pinn_handle *h, const float *theta, const float *x, co
 int pinn_adam(pinn_handle *h, float *theta, const float *grad, float *m, float *v,
               int32_t *step_count, double lr, double beta1, double beta2, double eps,
               uint64_t trainable_mask, float *best_theta, float *best_loss, void *stream);
+
+/* Reduction and Adam in ONE launch for the single-device step (no exchange between the two; same reference lines as
+ * pinn_adam): call pinn_residual_fwd_bwd with out == NULL -- the per-block partial sums then stay in the handle -- and
+ * this instead of pinn_adam.  grad_out (device float[P + 3], may be NULL) receives what pinn_residual_fwd_bwd would have
+ * written to out.  Bitwise the same gradient, losses and parameters as the two-call form (same additions, same order);
+ * the frozen-tensor mask is the one given to that pinn_residual_fwd_bwd call.  PINN_ERR_ARG if no such call precedes it. */
+int pinn_adam_fused(pinn_handle *h, float *theta, float *grad_out, float *m, float *v, int32_t *step_count,
+                    double lr, double beta1, double beta2, double eps, float *best_theta, float *best_loss,
+                    void *stream);
 
 /* pinn_adam for a rank of a data-parallel job: the step that consumes the all-reduced message also stores its two
  * trailing floats (msg_counts: the global boundary-set sizes of the batch drawn ahead, summed over ranks; exact

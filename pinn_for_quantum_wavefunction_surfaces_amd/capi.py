@@ -15,7 +15,7 @@ PINN_PREC_F32, PINN_PREC_BF16, PINN_PREC_BF16X3 = 0, 1, 2
 EXPORTS = ["pinn_param_count", "pinn_tensor_count", "pinn_tensor_layout", "pinn_strerror",
            "pinn_create", "pinn_destroy", "pinn_last_error", "pinn_sample", "pinn_forward",
            "pinn_residual_fwd_bwd", "pinn_adam", "pinn_sample_dp", "pinn_adam_dp", "pinn_profile_enable", "pinn_profile_read",
-           "pinn_debug_block_tiles",
+           "pinn_debug_block_tiles", "pinn_adam_fused",
            "pinn_energy_R", "pinn_quadrature3d", "pinn_xchg_create", "pinn_xchg_local_handle", "pinn_xchg_connect",
            "pinn_xchg_allreduce", "pinn_xchg_set_timeout", "pinn_xchg_status", "pinn_xchg_destroy", "pinn_xchg_last_error"]
 
@@ -74,6 +74,7 @@ def load_library():
     lib.pinn_residual_fwd_bwd.argtypes = [vp] + [fp] * 5 + [vp, C.c_int64, C.POINTER(Ham), i64p,
                                                              C.c_uint64, fp, vp]
     lib.pinn_adam.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_double] * 4 + [C.c_uint64, fp, fp, vp]
+    lib.pinn_adam_fused.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_double] * 4 + [fp, fp, vp]
     lib.pinn_adam_dp.argtypes = [vp, fp, fp, fp, fp, vp] + [C.c_double] * 4 + [C.c_uint64, fp, fp, fp, i64p, vp]
     lib.pinn_profile_enable.argtypes = [vp, C.c_int]
     lib.pinn_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
@@ -191,6 +192,12 @@ class Handle:
         ms = C.c_float()
         self._check(self.lib.pinn_profile_read(self.h, int(ncalls), C.byref(ms)), "pinn_profile_read")
         return float(ms.value)
+
+    def adam_fused(self, theta, grad_out, m, v, step_count, lr, b1, b2, eps, best_theta=None, best_loss=None):
+        """reduction + Adam in one launch, after residual_fwd_bwd(..., out=None) (include/pinn.h pinn_adam_fused)"""
+        self._check(self.lib.pinn_adam_fused(self.h, _ptr(theta), _ptr(grad_out), _ptr(m), _ptr(v), _ptr(step_count),
+                                             lr, b1, b2, eps, _ptr(best_theta), _ptr(best_loss), self._stream()),
+                    "pinn_adam_fused")
 
     def adam(self, theta, grad, m, v, step_count, lr, b1, b2, eps, trainable_mask,
              best_theta=None, best_loss=None, msg_counts=None, counts_out=None):

@@ -759,6 +759,25 @@ __global__ __launch_bounds__(kBlock, HE > 32 ? 1 : 2) void k_rnet_bwd(const floa
 // out[e] = sum_b partial[b][e]; frozen tensors -> 0.  Block = 64 entries x 16 row groups:
 // thread (tx, ty) sums rows ty, ty+16, ... of column e (coalesced over tx, 8 loads in
 // flight), then the 16 group sums are added in fixed order: bitwise reproducible.
+// rows ty, ty + 16, ... of column e of the partial sums (e < PT: trunk rows; < P: R-net rows; P .. P+2: the loss terms)
+__device__ __forceinline__ float column_part(const float* __restrict__ partT, int nbT, int strideT, int PT,
+                                             const float* __restrict__ partR, int nbR, int strideR, int P, int e, int ty)
+{
+    const float* src;
+    int nb, stride;
+    if (e < PT) { src = partT + e; nb = nbT; stride = strideT; }
+    else if (e < P) { src = partR + (e - PT); nb = nbR; stride = strideR; }
+    else { src = partT + PT + (e - P); nb = nbT; stride = strideT; }
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = ty;
+    for (; b + 16 * 7 < nb; b += 16 * 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] += src[(size_t)(b + 16 * k) * stride];
+    }
+    for (; b < nb; b += 16) a[0] += src[(size_t)b * stride];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 __global__ __launch_bounds__(1024) void k_reduce(const float* __restrict__ partT, int nbT, int strideT, int PT,
                                                  const float* __restrict__ partR, int nbR, int strideR, int PR,
                                                  const uint8_t* __restrict__ tensor_of, uint64_t trainable_mask,
@@ -769,21 +788,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const float* __restrict__ partT
     const int e = blockIdx.x * 64 + tx;
     const int P = PT + PR;
     float s = 0.f;
-    if (e < P + 3) {
-        const float* src;
-        int nb, stride;
-        if (e < PT) { src = partT + e; nb = nbT; stride = strideT; }
-        else if (e < P) { src = partR + (e - PT); nb = nbR; stride = strideR; }
-        else { src = partT + PT + (e - P); nb = nbT; stride = strideT; }
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int b = ty;
-        for (; b + 16 * 7 < nb; b += 16 * 8) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) a[k] += src[(size_t)(b + 16 * k) * stride];
-        }
-        for (; b < nb; b += 16) a[0] += src[(size_t)b * stride];
-        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
+    if (e < P + 3) s = column_part(partT, nbT, strideT, PT, partR, nbR, strideR, P, e, ty);
     sh[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && e < P + 3) {
@@ -853,6 +858,76 @@ __global__ __launch_bounds__(1024) void k_adam(float* __restrict__ theta,
                 counts_out[0] = (long long)msg_counts[0];
                 counts_out[1] = (long long)msg_counts[1];
             }
+        }
+    }
+}
+
+// k_reduce and k_adam in one launch, for the single-device step (no exchange between the two): block = 64 columns x 16 row
+// groups as in k_reduce; every block also sums the three loss columns (it needs the loss for the best-model test: 3 x nbT
+// floats, nothing), then row group 0 applies Adam to its 64 parameters.  Same additions in the same order as the two
+// kernels: bitwise identical gradient, losses and parameters.  step_count / best_loss: as in k_adam (ticket).
+__global__ __launch_bounds__(1024) void k_reduce_adam(const float* __restrict__ partT, int nbT, int strideT, int PT,
+                                                      const float* __restrict__ partR, int nbR, int strideR, int PR,
+                                                      const uint8_t* __restrict__ tensor_of, uint64_t trainable_mask,
+                                                      float* __restrict__ grad_out, float* __restrict__ theta,
+                                                      float* __restrict__ m, float* __restrict__ v,
+                                                      int32_t* __restrict__ step_count, double lr, double b1d, double b2d,
+                                                      double epsd, float* __restrict__ best_theta,
+                                                      float* __restrict__ best_loss, unsigned* __restrict__ ticket)
+{
+    __shared__ float sh[16][64], shl[16][4];
+    __shared__ float sh_step_size, sh_inv_bc2s, sh_best;
+    __shared__ int sh_step;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + tx;
+    const int P = PT + PR;
+    sh[ty][tx] = e < P + 3 ? column_part(partT, nbT, strideT, PT, partR, nbR, strideR, P, e, ty) : 0.f;
+    if (tx < 3) shl[ty][tx] = column_part(partT, nbT, strideT, PT, partR, nbR, strideR, P, P + tx, ty);
+    if (threadIdx.x == 0) {
+        const int step0 = *step_count + 1;
+        const double bc1 = 1.0 - pow(b1d, (double)step0);
+        const double bc2 = 1.0 - pow(b2d, (double)step0);
+        sh_step_size = (float)(lr / bc1);
+        sh_inv_bc2s = (float)(1.0 / sqrt(bc2));
+        sh_step = step0;
+        sh_best = best_loss ? *best_loss : 0.f;
+    }
+    __syncthreads();      // thread 0 has read step_count / best_loss before this block writes anything or takes its ticket
+    float l3[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += shl[k][j];
+        l3[j] = t;
+    }
+    const float ltot = l3[0] + l3[1] + l3[2];
+    const bool better = best_loss != nullptr && ltot < sh_best;
+    if (ty == 0 && e < P + 3) {
+        float g = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) g += sh[k][tx];
+        if (e < P && !((trainable_mask >> tensor_of[e]) & 1)) g = 0.f;
+        if (grad_out) grad_out[e] = g;
+        if (e < P) {
+            const float th = theta[e];
+            if (better && best_theta) best_theta[e] = th;     // train.py:58-60: params the loss was taken at
+            if ((trainable_mask >> tensor_of[e]) & 1) {
+                const float b1 = (float)b1d, b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
+                const float mk = b1 * m[e] + omb1 * g;
+                const float vk = b2 * v[e] + omb2 * g * g;
+                m[e] = mk;
+                v[e] = vk;
+                const float denom = sqrtf(vk) * sh_inv_bc2s + (float)epsd;
+                theta[e] = th - sh_step_size * (mk / denom);
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {   // every block has read step_count / best_loss by now
+            *ticket = 0;
+            *step_count = sh_step;
+            if (better) *best_loss = ltot;
         }
     }
 }
@@ -1056,6 +1131,8 @@ struct pinn_handle {
     int PT, PR, P;
     int nbT, nbR;           // persistent grid sizes
     int cus, bpcT;          // CUs of the device, resident trunk blocks per CU the grid is sized for
+    int pend_gT, pend_gR;   // > 0: partial sums of a pinn_residual_fwd_bwd call with out == NULL wait for pinn_adam_fused
+    uint64_t pend_mask;
     int strideT, strideR;
     float *E, *g, *Eb, *gb; // per-point scratch
     float *partT, *partR;   // per-block partials
@@ -1604,7 +1681,7 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
 {
     int rc = check_common(h, theta, x, y, z, R, n, ham);
     if (rc) return rc;
-    if (!out) return fail(h, PINN_ERR_ARG, "out is null");
+    h->pend_gT = h->pend_gR = 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     const pinn_arch& a = h->arch;
@@ -1642,6 +1719,10 @@ extern "C" int pinn_residual_fwd_bwd(pinn_handle* h, const float* theta, const f
     else if (!launch_rnet_bwd(a.HE, a.HG, a.act, theta + h->PT, h->thT + h->PT, R, h->Eb, h->gb, n, h->partR, h->strideR, gR, st, &e))
         return fail(h, PINN_ERR_UNSUPPORTED, "no R-net kernel for this (HE, HG)");
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_rnet_bwd", e);
+    if (!out) {      // the per-block partial sums stay in the handle: pinn_adam_fused reduces them and steps in one launch
+        h->pend_gT = gT; h->pend_gR = gR; h->pend_mask = trainable_mask;
+        return PINN_OK;
+    }
     const int tot = h->P + 3;
     hipLaunchKernelGGL(k_reduce, dim3((tot + 63) / 64), dim3(1024), 0, st, h->partT, gT, h->strideT,
                        h->PT, h->partR, gR, h->strideR, h->PR, h->tensor_of, trainable_mask, out);
@@ -1665,6 +1746,24 @@ extern "C" int pinn_adam_dp(pinn_handle* h, float* theta, const float* grad, flo
                        reinterpret_cast<long long*>(counts_out));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_adam", e);
+    return PINN_OK;
+}
+
+extern "C" int pinn_adam_fused(pinn_handle* h, float* theta, float* grad_out, float* m, float* v, int32_t* step_count,
+                               double lr, double beta1, double beta2, double eps, float* best_theta, float* best_loss,
+                               void* stream)
+{
+    if (!h) return PINN_ERR_ARG;
+    if (!theta || !m || !v || !step_count) return fail(h, PINN_ERR_ARG, "null pointer");
+    if (h->pend_gT <= 0) return fail(h, PINN_ERR_ARG, "pinn_adam_fused: no pinn_residual_fwd_bwd call with out == NULL before it");
+    const int tot = h->P + 3;
+    hipLaunchKernelGGL(k_reduce_adam, dim3((tot + 63) / 64), dim3(1024), 0, (hipStream_t)stream, h->partT, h->pend_gT,
+                       h->strideT, h->PT, h->partR, h->pend_gR, h->strideR, h->PR, h->tensor_of, h->pend_mask, grad_out,
+                       theta, m, v, step_count, lr, beta1, beta2, eps, best_theta, best_loss,
+                       reinterpret_cast<unsigned*>(h->samp + 2 * kSampleMaxBlocks + 1));
+    h->pend_gT = h->pend_gR = 0;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, PINN_ERR_HIP, "k_reduce_adam", e);
     return PINN_OK;
 }
 

@@ -85,6 +85,8 @@ class Trainer:
         # pinn_adam); True = poc/main.py:414-417 (the parameters AFTER that step's update, with the
         # optimizer state of that moment, as saveModel stores them)
         self.best_post_step = False
+        # reduction + Adam as one launch (pinn_adam_fused) where no exchange sits between them; PINN_FUSE_ADAM=0: two calls
+        self.fuse_adam = os.environ.get("PINN_FUSE_ADAM", "1") != "0"
         self.best_m = self.best_v = None
         self.best_step = torch.zeros(1, device=dev, dtype=torch.int32)
         # one-message pipelining needs exact float counts
@@ -153,8 +155,15 @@ class Trainer:
         cur = self._cur
         x, y, z, R, mask = self._pts[cur]
         ham = self.model.ham(self.plan.invN, 0.0, 0.0)
+        # single device, best model tracked by the Adam kernel itself (or not at all): reduction and Adam are one launch
+        fused = self.fuse_adam and not self.plan.collectives and not (track_best and self.best_post_step)
         self.h.residual_fwd_bwd(self.theta, x, y, z, R, mask, self.n, ham, self._cnt[cur],
-                                self.tmask, self.grad)
+                                self.tmask, None if fused else self.grad)
+        if fused:
+            self.h.adam_fused(self.theta, self.grad, self.m, self.v, self.step_count, self.lr, self.b1, self.b2, self.eps,
+                              self.best_theta if track_best else None, self.best_loss if track_best else None)
+            self.t += 1
+            return
         k = int(next_resample or 0)
         # points of step t + k and their local counts -- unless an earlier step already drew them (with
         # sc_sampling > 1 the driver hints at the same step twice: at the resampling step and at t+k-1)

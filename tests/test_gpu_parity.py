@@ -1011,6 +1011,46 @@ def test_unequal_tile_shares_only_reorder_the_sums(H, L, prec, monkeypatch):
         assert rel(out[share][:P], ref[:P]) < 2e-5, share
 
 
+@pytest.mark.parametrize("frozen", [False, True])
+def test_fused_reduce_adam_is_bitwise_the_two_call_form(golden_dir, frozen):
+    """pinn_adam_fused (round 4: reduction and Adam in one launch for the single-device step) after
+    pinn_residual_fwd_bwd(out = NULL) leaves the same bits in the gradient, the loss terms, theta, m, v, the step counter
+    and the best-model snapshot as pinn_residual_fwd_bwd(out) + pinn_adam -- over three steps (bias corrections), with and
+    without frozen tensors; without a pending call it reports PINN_ERR_ARG."""
+    g = np.load(os.path.join(golden_dir, "g2_formA_rand16.npz"))
+    arch, f = make()
+    n = len(g["x"])
+    mask = g["mask"]
+    n1, n2 = int((mask & 1).sum()), int(((mask >> 1) & 1).sum())
+    tmask = sum(1 << t for t in range(6, 12)) if frozen else (1 << 63) - 1
+    dev = [dev32(g[k]) for k in ("x", "y", "z", "R")]
+    dmask = torch.tensor(mask, device=DEV)
+    res = []
+    for fused in (False, True):
+        h = capi.Handle(arch, 0, 4096)
+        P = h.P
+        theta = dev32(g["theta"]).clone()
+        m, v = torch.zeros(P, device=DEV), torch.zeros(P, device=DEV)
+        grad = torch.zeros(P + 3, device=DEV)
+        step = torch.zeros(1, device=DEV, dtype=torch.int32)
+        best_theta, best_loss = torch.zeros(P, device=DEV), torch.full((1,), float("inf"), device=DEV)
+        if fused:
+            with pytest.raises(capi.PinnError):
+                h.adam_fused(theta, grad, m, v, step, 8e-3, 0.9, 0.999, 1e-8, best_theta, best_loss)
+        for _ in range(3):
+            if fused:
+                h.residual_fwd_bwd(theta, *dev, dmask, n, ham_of(f, n, n1, n2), None, tmask, None)
+                h.adam_fused(theta, grad, m, v, step, 8e-3, 0.9, 0.999, 1e-8, best_theta, best_loss)
+            else:
+                h.residual_fwd_bwd(theta, *dev, dmask, n, ham_of(f, n, n1, n2), None, tmask, grad)
+                h.adam(theta, grad, m, v, step, 8e-3, 0.9, 0.999, 1e-8, tmask, best_theta, best_loss)
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy().copy() for t in (grad, theta, m, v, step, best_theta, best_loss)])
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    assert int(res[1][4][0]) == 3 and np.isfinite(res[1][1]).all()
+
+
 def test_four_class_tile_shares_only_reorder_the_sums(golden_dir, monkeypatch):
     """The kernels with FOUR resident blocks per CU (k_trunk16's forward-only sweeps: fine-tune and pinn_forward; the R-net
     forward kernel) give the four arrival classes geometric shares 1 : q : q^2 : q^3 at a full grid (PINN_SHARE_Q, PINN_RNET_Q).

@@ -111,8 +111,18 @@ class OracleHandle:
                               invN=float(ham.invN), invN1=1.0 / c[0] if c[0] else 0.0,
                               invN2=1.0 / c[1] if c[1] else 0.0, trainable_mask=tmask)
         s = lg["sums"]
-        out.copy_(torch.tensor(np.concatenate([lg["grad"], [s[0] * ham.invN, s[1] / max(c[0], 1),
-                                                            s[2] / max(c[1], 1)]]), dtype=torch.float32))
+        res = torch.tensor(np.concatenate([lg["grad"], [s[0] * ham.invN, s[1] / max(c[0], 1),
+                                                        s[2] / max(c[1], 1)]]), dtype=torch.float32)
+        if out is None:                                # pinn_adam_fused follows (single-device step)
+            self.pending = (res, tmask)
+        else:
+            out.copy_(res)
+
+    def adam_fused(self, theta, grad_out, m, v, step_count, lr, b1, b2, eps, best_theta=None, best_loss=None):
+        res, tmask = self.pending
+        self.pending = None
+        grad_out.copy_(res)
+        self.adam(theta, grad_out, m, v, step_count, lr, b1, b2, eps, tmask, best_theta, best_loss)
 
     def adam(self, theta, grad, m, v, step_count, lr, b1, b2, eps, tmask, best_theta=None, best_loss=None,
              msg_counts=None, counts_out=None):

@@ -1381,7 +1381,7 @@ static int trunk_grid(const pinn_handle* h, int64_t n, int mode)
 // TileShares (pinn_common.h) of a launch.  Unequal shares only for full grids of two or four resident blocks per CU, where
 // blocks b, b + G/K, ... share a CU.  Shares measured per kernel family on MI355X (round 4, tools/share_sweep.sh, 1M points;
 // +-0.02 off the optimum costs ~1 %): k_trunk2<64> 0.665 (0.426 -> 0.397 ms), k_trunk2s<64> 0.625 (0.265 -> 0.245),
-// k_trunkD<64,4> 0.66 (1.052 -> 0.975), k_trunk16's reverse kernel 0.72 (0.181 -> 0.165: its waves share no barrier, the
+// k_trunkD<64,4> 0.65 (1.052 -> 0.975 at 0.66 on one box, 0.986 at 0.64-0.65 against 0.997 at 0.66 on another), k_trunk16's reverse kernel 0.72 (0.181 -> 0.165: its waves share no barrier, the
 // older block's lead is larger), the R-net reverse kernel 0.68.  Four blocks per CU (k_trunk16's forward-only sweeps, the
 // R-net forward kernel): geometric shares 1 : q : q^2 : q^3.  PINN_OLDER_SHARE / PINN_RNET_SHARE / PINN_SHARE_Q override
 // (0.5 / 0.5 / 1.0 = rounds 1-3); read once per process, except under PINN_MFMA_VARIANT_LIVE=1 (tests and tools switch them).
@@ -1426,7 +1426,7 @@ static TileShares trunk_shares(const pinn_handle* h, int64_t n, int grid, int mo
     if (grid == 4 * h->cus && t16 && mode != MODE_BWD)            // k_trunk16's forward-only sweeps: four blocks per CU
         return shares_four(n, forced_q > 0.0 ? forced_q : kShareQ16);
     if (grid != 2 * h->cus || mode != MODE_BWD || (a.precision == PINN_PREC_F32 && !t16)) return TileShares{};
-    double share = t16 ? 0.72 : (a.L == 4 ? 0.66 : (a.n_pass == 1 ? 0.625 : 0.665));
+    double share = t16 ? 0.72 : (a.L == 4 ? 0.65 : (a.n_pass == 1 ? 0.625 : 0.665));
     if (forced > 0.0) share = forced;
     return shares_two(n, share);
 }

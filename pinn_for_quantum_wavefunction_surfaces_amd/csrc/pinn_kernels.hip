@@ -1012,7 +1012,11 @@ __global__ __launch_bounds__(kSampleBlock) void k_sample(uint64_t seed, uint64_t
         if (threadIdx.x == 0) {
             __hip_atomic_store(&part[2 * blockIdx.x], (unsigned long long)sh[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&part[2 * blockIdx.x + 1], (unsigned long long)sh[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
+            // The two stores above are agent-scope atomic stores (write-through, sc1): once the wave's store counter
+            // has drained they are visible to every XCD, which is all the ticket below must wait for.  (__threadfence()
+            // here was a release fence for EVERYTHING this block wrote: buffer_wbl2 + buffer_inv, i.e. one write-back
+            // of the XCD's L2 -- full of the batch just sampled -- per block: most of this kernel's 15 us at 1M points.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             last = atomicAdd(reinterpret_cast<unsigned*>(part + 2 * kSampleMaxBlocks), 1u) == gridDim.x - 1;
         }
         __syncthreads();

@@ -1011,6 +1011,26 @@ def test_unequal_tile_shares_only_reorder_the_sums(H, L, prec, monkeypatch):
         assert rel(out[share][:P], ref[:P]) < 2e-5, share
 
 
+def test_sampler_set_sizes_over_many_calls_and_batch_sizes():
+    """The sampler hands its per-block boundary-set counts to whichever block finishes last (ticket).  Round 4 replaced the
+    release fence of every block by a wait for the block's own two agent-scope stores (the fence wrote the XCD's L2 back once
+    per block): 400 calls with batch sizes from 1 to 2^20 -- the int64 and the float counts against the mask bits summed on
+    the device, every call (tests/diag/diag_sample_counts.py runs thousands)."""
+    nmax = 1 << 20
+    h = capi.Handle(capi.Arch(16, 2, 32, 10, 0, 2, 1.0, capi.PINN_PREC_F32), 0, nmax)
+    x, y, z, R = [torch.empty(nmax, device=DEV) for _ in range(4)]
+    mask = torch.empty(nmax, device=DEV, dtype=torch.uint8)
+    counts = torch.zeros(2, device=DEV, dtype=torch.int64)
+    cf = torch.zeros(2, device=DEV)
+    g = torch.Generator().manual_seed(1)
+    for it in range(400):
+        n = int(torch.randint(1, nmax + 1, (1,), generator=g)) if it % 3 else nmax
+        h.sample(12345, it, 0, n, 18.0, 0.2, 4.0, 0.1, 12.0, x, y, z, R, mask, counts, counts_f32=cf)
+        ref = torch.stack([(mask[:n] & 1).sum(), ((mask[:n] >> 1) & 1).sum()]).to(torch.int64)
+        assert torch.equal(counts, ref) and torch.equal(cf.to(torch.int64), ref), (it, n, counts.tolist(), ref.tolist())
+        assert int(ref[0]) > 0 or n < 64
+
+
 @pytest.mark.parametrize("frozen", [False, True])
 def test_fused_reduce_adam_is_bitwise_the_two_call_form(golden_dir, frozen):
     """pinn_adam_fused (round 4: reduction and Adam in one launch for the single-device step) after

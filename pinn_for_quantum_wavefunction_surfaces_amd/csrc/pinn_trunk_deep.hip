@@ -90,7 +90,6 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     const int lane = threadIdx.x & 63;
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row tile owned by this wave
     const int g = lane >> 4, c = lane & 15;
-    const int lane16 = lane * 16;
     // Slot of lane (g, c) inside a 1 KB (k chunk, stream) block of an exchange buffer: lane-linear, or (SWZ) with the
     // 16-byte slots of the odd lane groups permuted by c ^ 12.  The transposed reads of the weight gradient fetch, per
     // 32-lane service group, the slots c' in {0-3, 8-11} (then {4-7, 12-15}) of TWO adjacent lane groups, which the
@@ -98,12 +97,20 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     // eight waves read 2 x 36 fragments per layer and tile); c ^ 12 moves the odd group's to the other banks and keeps
     // the 16-byte fragment reads (hardware groups {0-3, 12-15, 20-27}, ...) and the 8-byte stores conflict-free.
     auto slot16 = [](int gg, int cc) { return (gg * 16 + (SWZ ? (cc ^ ((gg & 1) * 12)) : cc)) * 16; };
-    const int sw16 = slot16(g, c);
-    const int own_slot = sw16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);
+    // LEAN (H = 128, where the kernel spills): address values that can be rebuilt from sw16 / trl with one to three VALU
+    // instructions are rebuilt where they are used instead of occupying registers for the whole kernel -- scratch
+    // 128 -> 76 B/lane, 3.59 -> 3.34 ms per 1M points (steady A/B, round 4); at H = 64 (no spills) the same costs 1 %.
+    constexpr bool LEAN = C::STASH;
+    const int sw16 = SWZ ? slot16(g, c) : lane * 16;
+    const int own_slot = sw16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);     // (rebuilding this one too: no gain)
+    const int lane16_r = lane * 16;
     // transposed read: this lane fetches half (c & 1) of the slot of source lane (g' = (c & 3) >> 1 [+ 2 (T & 1)],
     // c' = 8 (g & 1) + (c >> 2) [+ 4 for the second read]) of stream pair member g >> 1
     const int trl = (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2)) + (c & 1) * 8;
-    const int trh = SWZ ? (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2) + 4) + (c & 1) * 8 : trl + 64;
+    // (the second transposed read of a fragment is at slot c' + 4: 64 bytes above the first for even source groups, 64
+    // below for odd ones with swizzled slots -- the first address with bit 6 flipped either way: LEAN forms it by one
+    // v_xor per weight-gradient phase instead of keeping it in a register)
+    const int trh_r = SWZ ? trl ^ 64 : trl;
     const int n0 = 16 * part + 4 * g;                                    // first own neuron of this lane
 
     for (int k = threadIdx.x; k < H; k += NT) {
@@ -127,6 +134,9 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     // register of the weight and stash accesses is lane16)
     const int wsoff = part * KC * 1024;
     auto loadA = [&](int m, bf16x8 (&a)[KC]) {
+        int lane16 = lane16_r;  // the packed weights are lane-linear: with swizzled slots the offset is rebuilt from sw16 here
+        if constexpr (SWZ && LEAN)
+            asm volatile("v_bfe_u32 %0, %1, 8, 1\n\tv_mul_u32_u24 %0, 0xc0, %0\n\tv_xor_b32 %0, %0, %1" : "=&v"(lane16) : "v"(sw16));
 #pragma unroll
         for (int kc = 0; kc < KC; kc++)
             a[kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + kc * 1024, wsoff + m * H * H * 2, 0));
@@ -137,10 +147,10 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     const int ssoff = (int)(blockIdx.x * C::STASH_BLOCK) + part * 4096;
     auto stash_so = [&](int l) { return ssoff + (l - 1) * C::STASH_LAYER; };
     auto stash_put = [&](int l, int k, u32x4 v) {
-        __builtin_amdgcn_raw_buffer_store_b128(v, srs, lane16 + k * 1024, stash_so(l), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, srs, sw16 + k * 1024, stash_so(l), 0);
     };
     auto stash_get = [&](int l, int k) {
-        return __builtin_amdgcn_raw_buffer_load_b128(srs, lane16 + k * 1024, stash_so(l), 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(srs, sw16 + k * 1024, stash_so(l), 0);
     };
 
     f32x4 wacc[NW][HT], bacc[L], w0acc0 = splat(0.f), w0acc1 = splat(0.f), woacc = splat(0.f);
@@ -191,10 +201,10 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     auto bfrag = [&](lds_p eb, int kc, int s) {
         return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(eb + sw16 + (kc * NST + s) * 1024);
     };
-    auto trfrag = [&](lds_p eb, int T, int ph) {     // rows 32ph..32ph+31 of the [column][neuron] image, tile T
+    auto trfrag = [&](lds_p eb, int trh, int T, int ph) {     // rows 32ph..32ph+31 of the [column][neuron] image, tile T
         const int o = ph * 2048 + (T >> 1) * NST * 1024 + (T & 1) * 512;
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trl + o));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trh + o));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(eb + trh + o + (SWZ ? 0 : 64)));
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
     // D[own 16 rows][NST column tiles of ONE pass] += A x B: A fragments in registers, B fragments from the pass
@@ -228,11 +238,13 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         constexpr int WG = 4;
         constexpr int GPK = HT / WG, NG = NST * GPK;
         bf16x8 fy[2], fx[2][WG];
+        int trh = trh_r;
+        if constexpr (SWZ && LEAN) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(trh) : "v"(trl));   // not hoisted out of the tile loop
         auto fetch = [&](int j, bf16x8 (&x)[WG]) {
             const int k = j / GPK, i0 = (j % GPK) * WG;
-            if (j % GPK == 0) fy[k & 1] = trfrag(yb + (k >> 1) * EB, part, k & 1);
+            if (j % GPK == 0) fy[k & 1] = trfrag(yb + (k >> 1) * EB, trh, part, k & 1);
 #pragma unroll
-            for (int i = 0; i < WG; i++) x[i] = trfrag(xb + (k >> 1) * EB, i0 + i, k & 1);
+            for (int i = 0; i < WG; i++) x[i] = trfrag(xb + (k >> 1) * EB, trh, i0 + i, k & 1);
         };
         fetch(0, fx[0]);
 #pragma unroll

@@ -104,6 +104,13 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     const int sw16 = SWZ ? slot16(g, c) : lane * 16;
     const int own_slot = sw16 + (part >> 1) * NST * 64 * 16 + 8 * (part & 1);     // (rebuilding this one too: no gain)
     const int lane16_r = lane * 16;
+    // the lane's column c and lane group g where the tile loop needs them: v_mbcnt (2 instructions) instead of a register
+    // that hipcc spills before the loop and reloads in every trip (LEAN)
+    auto lane_now = [&]() {
+        int l = lane;
+        if constexpr (LEAN) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
     // transposed read: this lane fetches half (c & 1) of the slot of source lane (g' = (c & 3) >> 1 [+ 2 (T & 1)],
     // c' = 8 (g & 1) + (c >> 2) [+ 4 for the second read]) of stream pair member g >> 1
     const int trl = (g >> 1) * 1024 + slot16((c & 3) >> 1, 8 * (g & 1) + (c >> 2)) + (c & 1) * 8;
@@ -258,7 +265,7 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
         }
     };
     auto ring_in = [&](int slot, float (&inA)[2][NST]) {
-        const float* rp = ring + (slot * 16 + c) * RECF;
+        const float* rp = ring + (slot * 16 + (lane_now() & 15)) * RECF;
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
         for (int s = 0; s < NST; s++) { inA[0][s] = r0[s]; inA[1][s] = r1[s]; }
@@ -283,8 +290,6 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
     const unsigned long long life1 = PINN_LIFE_NOW();
     for (int64_t itx = 0; itx < iters; itx++) {
         const int64_t tile = tfirst + itx * tstride;
-        const int64_t idx = tile * 16 + c;
-        const bool valid = tile < tend && idx < A.n;
         const int slot = (int)(itx % RB);
         if (slot == 0) {
             if (itx) __syncthreads();           // the last reverse step of the previous trip read the old batch
@@ -379,7 +384,10 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             }
             if (l == L - 1) {
                 const float tot = xg_sum_pair(Sv, Sl);          // Sv in lane groups 0,1; Sl in groups 2,3
-                if ((g & 1) == 0) SB[(part * 16 + c) * 2 + (g >> 1)] = tot;
+                {
+                    const int ln = lane_now(), cc = ln & 15, gg = ln >> 4;
+                    if ((gg & 1) == 0) SB[(part * 16 + cc) * 2 + (gg >> 1)] = tot;
+                }
             }
             TD_STAMP(2 * l);
             __syncthreads();
@@ -391,6 +399,9 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
             {
                 float inA[2][NST];
                 ring_in(slot, inA);
+                const int ln = lane_now(), c = ln & 15, g = ln >> 4;
+                const int64_t idx = tile * 16 + c;
+                const bool valid = tile < tend && idx < A.n;
                 const f32x4 r2 = *reinterpret_cast<const f32x4*>(ring + (slot * 16 + c) * RECF + 8);
                 const unsigned mkpt = (unsigned)r2[3];
                 const float F = inA[0][0] + A.P * inA[1][0];

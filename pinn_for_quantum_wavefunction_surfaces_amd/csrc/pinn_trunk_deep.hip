@@ -273,7 +273,9 @@ void k_trunkD(const float* __restrict__ theta, const __bf16* __restrict__ wpk_g,
 
     const lds_p YB = lds0 + C::OFF_Y;
     // the raw points of a ring batch are requested a whole batch ahead (seven registers held for RB trips)
-    constexpr bool RPF = true;   // (false: load at the refill, 7 registers less, measured 1.5 % slower at 4x128)
+    // (H = 128: loaded at the refill instead -- seven registers less through sixteen trips, scratch 68 -> 24 B/lane, 3.21 ->
+    // 3.17 ms; before the other register savings of round 4 the same switch measured 1.5 % SLOWER.  H = 64: no difference.)
+    constexpr bool RPF = !C::STASH;
     PointRec nxt;
     if (RPF) nxt = load_rec(0);
     bf16x8 afr[KC];
